@@ -1,0 +1,143 @@
+"""The CPU oracle (oracle/cdl_oracle.py) replayed against fixtures generated from the
+unmodified reference (tools/make_golden.py).  This is what pins the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cdl_oracle as O
+
+TOL = 2e-6      # same ATen kernels on the same machine family -> essentially bit equal
+
+
+def hyper(g):
+    K, M, P, s, C = g["hyper"]
+    P = tuple(g["P3"]) if "P3" in g else P
+    return K, M, P, s, C
+
+
+CASES = [
+    ("f1_2d_s1", 2, False), ("f2_2d_s2_odd", 2, False), ("f3_jdd_c3_mask", 2, False),
+    ("f3b_jdd_s2_odd", 2, False), ("f4a_3d_p555", 3, False), ("f4b_3d_p995_s2", 3, False),
+    ("f4c_3d_s2_odd", 3, False), ("f5_gabor_shared", 2, True), ("f5b_gabor_plain", 2, True),
+    ("f6_negative_t", 2, False),
+]
+
+
+@pytest.mark.parametrize("name,ndim,gabor", CASES)
+def test_forward_matches_reference(name, ndim, gabor):
+    g = load_golden(name)
+    K, M, P, s, C = hyper(g)
+    adaptive = name != "f5b_gabor_plain"
+    xhat, codes = O.ista(g["sd"], g["y"], K=K, P=P, s=s, sigma=g["sigma"], adaptive=adaptive,
+                         mask=g.get("mask"), ndim=ndim, gabor=gabor, all_codes=True)
+    assert xhat.shape == g["xhat"].shape
+    assert rel_err(xhat, g["xhat"]) < TOL
+    if "z" in g:
+        assert rel_err(codes[-1], g["z"]) < TOL
+    for k in range(K):
+        if f"code{k}" in g:
+            assert rel_err(codes[k], g[f"code{k}"]) < TOL
+    assert abs(float(torch.mean((g["x"] - xhat) ** 2)) - g["loss"]) < 1e-7
+
+
+@pytest.mark.parametrize("name,ndim,gabor", CASES)
+def test_grads_match_reference(name, ndim, gabor):
+    g = load_golden(name)
+    K, M, P, s, C = hyper(g)
+    sd = dict(g["sd"])
+    if gabor:      # rebuild the reference's parameter aliasing from the `shared` string
+        sd = O.gabor_alias(sd, K, g["shared"])
+    adaptive = name != "f5b_gabor_plain"
+    loss, grads, _ = O.loss_and_grads(sd, g["x"], g["y"], K=K, P=P, s=s, sigma=g["sigma"],
+                                      adaptive=adaptive, mask=g.get("mask"), ndim=ndim, gabor=gabor)
+    assert abs(loss - g["loss"]) < 1e-7
+    checked = 0
+    for key, ref in g["grad"].items():
+        got = grads.get(key)
+        assert got is not None, key
+        assert rel_err(got, ref) < 5e-5, key
+        checked += 1
+    assert checked >= 3
+    assert "g" not in g["grad"]          # the unused parameter g receives no gradient
+
+
+def test_gabor_filters(golden):
+    g = golden("f5_gabor_shared")
+    for k in range(3):
+        fa = O.gabor_bank(*(g["sd"][f"A.{k}.{f}"] for f in ("alpha", "a", "w0", "psi")), 7, True)
+        fb = O.gabor_bank(*(g["sd"][f"B.{k}.{f}"] for f in ("alpha", "a", "w0", "psi")), 7, False)
+        assert rel_err(fa, g["filt"][f"A.{k}"]) < TOL
+        assert rel_err(fb, g["filt"][f"B.{k}"]) < TOL
+
+
+def test_shrinkage_table(golden):
+    g = golden("f6_negative_t")
+    for row, t in zip(g["st_out"], g["st_t"].tolist()):
+        assert torch.equal(O.soft_threshold(g["st_in"], torch.tensor(t, dtype=torch.float32)), row)
+
+
+def test_generator_last_item_is_xhat(golden):
+    g = golden("f1_2d_s1")
+    assert rel_err(g["gen_xhat"], g["xhat"]) == 0.0
+
+
+@pytest.mark.parametrize("name,ndim", [("f7_train_step", 2), ("f7b_train_step_3d", 3)])
+def test_train_step(name, ndim):
+    g = load_golden(name)
+    K, M, P, s, C = hyper(g)
+    loss, grads, new = O.train_step(g["sd"], g["x"], g["y"], K=K, P=P, s=s, sigma=g["sigma"],
+                                    adaptive=True, ndim=ndim, lr=g["lr"], clip=g["clip"],
+                                    project=(ndim == 2))
+    assert abs(loss - g["loss"]) < 1e-7
+    for key, ref in g["grad"].items():
+        assert rel_err(grads[key], ref) < 5e-5, key
+    for key, ref in g["after"].items():
+        if key in new:
+            assert rel_err(new[key], ref) < 1e-5, key
+
+
+def test_init_matches_reference_seed(golden):
+    """Same seed, same RNG consumption order -> same W and same power-method L."""
+    g = golden("f8_init_2d")
+    K, M, P, s, C = g["hyper"]
+    torch.manual_seed(g["seed"])
+    burn_default_inits(K, M, P, s, C, 2)
+    sd, L = O.init_dictionary(K, M, P, s, C, g["t0"], ndim=2)
+    for key in ("A.0.weight", "B.1.weight", "t", "g"):
+        assert rel_err(sd[key], g["sd"][key]) < 1e-6, key
+    g = golden("f8_init_3d")
+    K, M, _, s, C = g["hyper"]
+    P = tuple(g["P3"])
+    torch.manual_seed(g["seed"])
+    burn_default_inits(K, M, P, s, C, 3)
+    sd, L = O.init_dictionary(K, M, P, s, C, g["t0"], ndim=3, depth=g["depth"])
+    for key in ("A.0.weight", "B.1.weight", "t"):
+        assert rel_err(sd[key], g["sd"][key]) < 1e-6, key
+
+
+def burn_default_inits(K, M, P, s, C, ndim):
+    """Consume the RNG draws of the K Conv + K ConvTranspose default initialisers."""
+    conv, convT = (torch.nn.Conv2d, torch.nn.ConvTranspose2d) if ndim == 2 else \
+                  (torch.nn.Conv3d, torch.nn.ConvTranspose3d)
+    for _ in range(K):
+        conv(C, M, P, bias=False)
+    for _ in range(K):
+        convT(M, C, P, bias=False)
+
+
+def test_helpers(golden):
+    g = golden("f9_helpers")
+    p2 = g["pads2"]
+    for i in range(5):
+        H, W, s = g["pads2_in"][3 * i:3 * i + 3]
+        assert list(O.stride_pads((H, W), s)) == p2[4 * i:4 * i + 4]
+    p3 = g["pads3"]
+    for i in range(3):
+        D, H, W, s = g["pads3_in"][4 * i:4 * i + 4]
+        assert list(O.stride_pads((D, H, W), s)) == p3[6 * i:6 * i + 6]
+    assert rel_err(O.unit_ball(g["W"], (2, 3)), g["W_proj"]) < 1e-7
+    assert torch.equal(O.bayer_mask(torch.zeros(1, 3, 6, 8)), g["bayer"])
+    # 3-D projection: the reference call raises on this torch (see tools/make_golden.py), so
+    # only the defining property is checked: parity unpinned.
+    w3 = O.unit_ball(g["W3"], (2, 3, 4))
+    assert float(torch.linalg.vector_norm(w3, dim=(2, 3, 4)).max()) <= 1 + 1e-6
