@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s denoised (fwd+bwd) at K=30, M=64, P=7 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" is one complete pass of the hot path over one batch: the reference's training step
+(train.py:76-102) -- awgn -> forward (K unrolled iterations) -> MSE -> backward -> gradient
+all-reduce (N>1) -> clip -> Adam -> project -- on a synthetic 64 x 1 x 256 x 256 batch per GPU
+(BASELINE configs[1]; weak scaling: every rank owns its own 64 images).  Inputs and weights are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                                    # noqa: E402
+import torch.distributed as dist                # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--K", type=int, default=30)
+    ap.add_argument("--M", type=int, default=64)
+    ap.add_argument("--P", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def event_ms(fn, reps):
+    """Average device time of `fn` over `reps` launches, HIP events on torch's current stream
+    (the stream every kernel of this package is enqueued on)."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def kernel_probe(cva, net, batch, size, reps=5):
+    """Time each kernel family of the step on the step's own shapes; returns the table and the
+    dominant one (largest launches-per-step x average duration) with its algorithmic bytes."""
+    o = cva.ops
+    K, M, P = net.K, net.M, net.P
+    N, C = batch, 1
+    g = o.Geometry.make(N, C, M, (size, size), (P, P), (P // 2, P // 2), 1)
+    dev = "cuda"
+    x = torch.randn(g.image_shape(), device=dev)
+    z = torch.randn(g.code_shape(), device=dev) * (torch.rand(g.code_shape(), device=dev) < 0.2)
+    gup = torch.randn(g.code_shape(), device=dev)
+    tau = torch.full((N, M), 0.01, device=dev)
+    w = net.A[1].weight.detach()
+    out = torch.empty(g.code_shape(), device=dev)
+    thin = torch.empty(g.image_shape(), device=dev)
+    dt = torch.zeros(2, M, device=dev)
+    fat = z.numel() * 4
+    th = x.numel() * 4
+    table = {
+        # name: (callable, launches per step, algorithmic bytes per launch)
+        "k_analysis(fwd iter: z'=ST(z-A r))": (lambda: o.analysis(g, x, w, -1.0, z, None, tau, out=out), K, 2 * fat + th),
+        "k_synthesis(fwd: r=Bz-yp)": (lambda: o.synthesis(g, z, w, 1.0, None, None, x, out=thin), K, fat + 2 * th),
+        "k_analysis(bwd: g=du+B^T q)": (lambda: o.analysis(g, x, w, 1.0, gup, z, None, out=out), K, 3 * fat + th),
+        "k_synthesis(bwd: q=-A^T du)": (lambda: o.synthesis(g, gup, w, -1.0, z, None, None, out=thin), K - 1, 2 * fat + th),
+        "k_wgrad(dA)": (lambda: o.wgrad(g, gup, x, -1.0, gate=z), K, 2 * fat + th),
+        "k_wgrad(dB)": (lambda: o.wgrad(g, z, x, 1.0), K, fat + th),
+        "k_tau_partial": (lambda: o.tau_grad(g, gup, z, None, dt), K, 2 * fat),
+    }
+    rows = {}
+    for name, (fn, count, nbytes) in table.items():
+        ms = event_ms(fn, reps)
+        rows[name] = {"ms": ms, "per_step": count, "bytes": nbytes,
+                      "GBps": nbytes / ms / 1e6, "share_ms": ms * count}
+    dom = max(rows, key=lambda k: rows[k]["share_ms"])
+    return rows, dom
+
+
+def cpu_baseline(sd, x, y, sigma, K, P, reps=2):
+    """The CPU oracle (PyTorch restatement of the reference, kind='port') timed on this host's cores
+    on a bounded sample of the same workload: fwd+bwd of `x.shape[0]` images."""
+    from oracle import cdl_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = dict(sd)
+    sd["D.weight"] = sd["B.0.weight"]
+    O.loss_and_grads(sd, x, y, K=K, P=P, s=1, sigma=sigma, adaptive=True)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss, grads, xhat = O.loss_and_grads(sd, x, y, K=K, P=P, s=1, sigma=sigma, adaptive=True)
+    dt = (time.perf_counter() - t0) / reps
+    pix = x.shape[0] * x.shape[2] * x.shape[3]
+    return pix / dt / 1e6, xhat, loss, torch.get_num_threads()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd.parallel import GradientBucket, broadcast_parameters
+
+    K, M, P, B, S = args.K, args.M, args.P, args.batch, args.size
+    torch.manual_seed(1)
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    sd_cpu = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    broadcast_parameters(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    bucket = GradientBucket(net.parameters())
+
+    # synthetic data, generated once and resident in HBM before timing (seeded per rank)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x_cpu = cva.utils.synthetic_clip((min(B, 8), 1, S, S), seed=rank)
+    x_cpu = x_cpu.repeat((B + x_cpu.shape[0] - 1) // x_cpu.shape[0], 1, 1, 1)[:B]
+    x = x_cpu.to(dev)
+    dgen = torch.Generator(device=dev).manual_seed(99 + rank)
+
+    def step():
+        loss, _ = cva.train_step(net, opt, x, 25, clip_grad=5e-2, project=True,
+                                 grad_sync=bucket.sync if world > 1 else None, generator=dgen)
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed * 1e3 / args.steps
+    pix_per_step = world * B * S * S
+    value = pix_per_step / (ms_per_step * 1e-3) / 1e6
+
+    # forward-only (inference) rate on the same batch, for BASELINE.md's fwd column
+    with torch.no_grad():
+        y_inf = x + torch.randn(x.shape, device=dev, generator=dgen) * 25 / 255
+        fwd_ms = event_ms(lambda: net(y_inf, 25.0), 2)
+    fwd_mpix = B * S * S / (fwd_ms * 1e-3) / 1e6
+
+    out = None
+    if rank == 0:
+        rows, dom = kernel_probe(cva, net, B, S)
+        d = rows[dom]
+        out = {
+            "metric": f"Mpix/s denoised (fwd+bwd) at K={K},M={M},P={P}",
+            "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CDLNet K={K} M={M} P={P} s=1 C=1 train step (fwd+bwd+Adam+project), "
+                                   f"batch {B}x1x{S}x{S} per GPU, sigma=25",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "fwd_only_mpix_s": round(fwd_mpix, 3), "fwd_ms": round(fwd_ms, 3),
+            "loss": float(loss),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(d["GBps"], 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 5),
+                         "traffic": None, "avg_ms": round(d["ms"], 4),
+                         "algorithmic_bytes_per_launch": d["bytes"]},
+            "kernels": {k: {"ms": round(v["ms"], 4), "per_step": v["per_step"],
+                            "GBps": round(v["GBps"], 1)} for k, v in rows.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nb = min(args.cpu_batch, B)
+            xs = x_cpu[:nb]
+            ys = xs + torch.randn(xs.shape, generator=gen) * 25 / 255
+            cpu_mpix, xref, lref, threads = cpu_baseline(sd_cpu, xs, ys, 25.0, K, P)
+            with torch.no_grad():
+                net0 = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=False)
+                net0.load_state_dict(sd_cpu)
+                xo, _ = net0.to(dev)(ys.to(dev), 25.0)
+            rel = float((xo.cpu() - xref).abs().max() / xref.abs().max())
+            out["cpu_baseline"] = {"value": round(cpu_mpix, 4), "unit": "Mpix/s", "cores": threads,
+                                   "kind": "port",
+                                   "sample": f"fwd+bwd of {nb}x1x{S}x{S} (same net, same noise model), "
+                                             f"oracle/cdl_oracle.py on torch CPU, 2 reps after 1 warm-up"}
+            out["parity"] = {"xhat_rel_err_vs_cpu": rel,
+                             "psnr_cpu": round(cva.psnr(xs, xref), 4),
+                             "psnr_gpu": round(cva.psnr(xs, xo.cpu()), 4),
+                             "psnr_noisy": round(cva.psnr(xs, ys), 4)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,18 @@
+"""cdlnet-video_amd: MI355X-native unrolled-ISTA hot path of RQLuo/CDLNet-video.
+
+Import as `cdlnet_video_amd` (see the loader shim at the repository root; the directory name
+carries a hyphen).  Public surface mirrors the reference's `model/net.py`.
+"""
+from . import _lib, ops, parallel, train, utils
+from ._lib import HipKernelError, HipLibraryMissing
+from .gabor import ConvAdjoint2dGabor
+from .net import ST, CDLNet, CDLNetVideo, GDLNet
+from .train import build_model, init_model, load_ckpt, save_ckpt, train_step
+from .utils import awgn, awgn3d, gen_bayer_mask, psnr
+
+JDD_CDLNet = CDLNet      # BASELINE.json config 4: CDLNet(C=3) + Bayer mask
+
+__all__ = ["CDLNet", "CDLNetVideo", "GDLNet", "JDD_CDLNet", "ConvAdjoint2dGabor", "ST",
+           "build_model", "init_model", "load_ckpt", "save_ckpt", "train_step",
+           "awgn", "awgn3d", "gen_bayer_mask", "psnr", "ops", "parallel", "train", "utils",
+           "HipLibraryMissing", "HipKernelError"]

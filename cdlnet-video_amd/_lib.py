@@ -1,0 +1,85 @@
+"""ctypes binding of libcdlnet_hip.so (C ABI declared in include/cdlnet_hip.h).
+
+The library is the product: there is no fallback.  `lib()` raises
+`HipLibraryMissing` when the shared object has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C cdlnet-video_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcdlnet_hip.so")
+
+CDL_EINVAL = -10001
+CDL_EUNSUPPORTED = -10002
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class Geom(ctypes.Structure):
+    """Mirror of `cdl_geom` (include/cdlnet_hip.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("N", "C", "M", "D", "H", "W", "Pd", "Ph", "Pw", "pd", "ph", "pw", "sd", "sh", "sw")]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_G = ctypes.POINTER(Geom)
+_IP = ctypes.POINTER(ctypes.c_int)
+
+# name -> argtypes; every function returns int except cdl_version
+SIGNATURES = {
+    "cdl_preprocess": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _IP, _P],
+    "cdl_postprocess": [_P, _P, _P, _I, _I, _I, _I, _I, _IP, _P],
+    "cdl_postprocess_bwd": [_P, _P, _I, _I, _I, _I, _I, _IP, _P],
+    "cdl_thresholds": [_P, _P, _P, _I, _I, _I, _P],
+    "cdl_shrink": [_P, _P, _P, _I, ctypes.c_size_t, _P],
+    "cdl_analysis": [_G, _P, _P, _F, _P, _P, _P, _P, _P],
+    "cdl_synthesis": [_G, _P, _P, _P, _F, _P, _P, _P, _P],
+    "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P],
+    "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
+    "cdl_project_filters": [_P, _I, _I, _P],
+    "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: the HIP kernels are the only compute path of this package; "
+                "build them with `make -C cdlnet-video_amd/csrc` (hipcc --offload-arch=gfx950).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here = header / library mismatch
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        handle.cdl_version.restype = ctypes.c_char_p
+        handle.cdl_version.argtypes = []
+        _lib = handle
+    return _lib
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc, name):
+    if rc == 0:
+        return
+    if rc == CDL_EINVAL:
+        raise HipKernelError(f"{name}: invalid argument (CDL_EINVAL)")
+    if rc == CDL_EUNSUPPORTED:
+        raise HipKernelError(f"{name}: shape not supported by this kernel (CDL_EUNSUPPORTED)")
+    raise HipKernelError(f"{name}: HIP runtime error {-rc}")

@@ -1,0 +1,615 @@
+// Shape-generic fp32 kernels (any C, M, odd P per axis, stride, 2-D or 3-D).
+// LDS-tiled direct correlation on the vector ALUs: the always-available path and the
+// on-device yardstick for the MFMA kernels in cdl_fused2d.hip.  One code path serves
+// CDLNet (D = 1), the Bayer-masked JDD variant (C = 3, mask), CDLNetVideo and GDLNet.
+#include "cdl_common.h"
+
+namespace {
+
+constexpr int TILE = 16;          // 16 x 16 output pixels per 256-thread workgroup
+constexpr int MCHUNK = 8;         // code channels accumulated per thread per pass
+
+// ------------------------------------------------------------------------------------------
+// analysis: acc[m] = sum_{c,kd,ki,kj} x[c, zd*sd-pd+kd, zy*sh-ph+ki, zx*sw-pw+kj] * w[m,c,kd,ki,kj]
+// One workgroup = one (n, zd, 16x16 tile of (zy,zx)); the image patch (all C, Pd slices, halo)
+// is staged once in LDS and reused for every code channel; filter taps are wave-uniform
+// scalar loads.
+__global__ __launch_bounds__(256) void k_analysis(cdl_geom g, const float *__restrict__ x,
+                                                  const float *__restrict__ w, float alpha,
+                                                  const float *__restrict__ zin,
+                                                  const float *__restrict__ gate,
+                                                  const float *__restrict__ tau,
+                                                  float *__restrict__ out, int tilesX, int tilesY)
+{
+    extern __shared__ float patch[];
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    const int PH = (TILE - 1) * g.sh + g.Ph, PW = (TILE - 1) * g.sw + g.Pw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b;
+    const int n = blockIdx.y;
+    const int ly = threadIdx.x / TILE, lx = threadIdx.x % TILE;
+    const int zy = ty * TILE + ly, zx = tx * TILE + lx;
+    const int y0 = ty * TILE * g.sh - g.ph, x0 = tx * TILE * g.sw - g.pw, d0 = zd * g.sd - g.pd;
+
+    const int plane = PH * PW, pvol = g.C * g.Pd * plane;
+    for (int i = threadIdx.x; i < pvol; i += 256) {
+        int px = i % PW, r = i / PW;
+        int py = r % PH; r /= PH;
+        int kd = r % g.Pd, c = r / g.Pd;
+        int d = d0 + kd, yy = y0 + py, xx = x0 + px;
+        float v = 0.0f;
+        if (d >= 0 && d < g.D && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+            v = x[((((size_t)n * g.C + c) * g.D + d) * g.H + yy) * g.W + xx];
+        patch[i] = v;
+    }
+    __syncthreads();
+
+    const int taps = g.Pd * g.Ph * g.Pw, wrow = g.C * taps;
+    const bool live = zy < Hz && zx < Wz;
+    const float *pbase = patch + (ly * g.sh) * PW + lx * g.sw;
+    for (int m0 = 0; m0 < g.M; m0 += MCHUNK) {
+        float acc[MCHUNK];
+#pragma unroll
+        for (int j = 0; j < MCHUNK; ++j) acc[j] = 0.0f;
+        const float *wp[MCHUNK];
+#pragma unroll
+        for (int j = 0; j < MCHUNK; ++j) wp[j] = w + (size_t)min(m0 + j, g.M - 1) * wrow;
+        int widx = 0;
+        for (int c = 0; c < g.C; ++c)
+            for (int kd = 0; kd < g.Pd; ++kd) {
+                const float *prow = pbase + (c * g.Pd + kd) * plane;
+                for (int ki = 0; ki < g.Ph; ++ki, prow += PW)
+                    for (int kj = 0; kj < g.Pw; ++kj, ++widx) {
+                        float v = prow[kj];
+#pragma unroll
+                        for (int j = 0; j < MCHUNK; ++j) acc[j] = fmaf(v, wp[j][widx], acc[j]);
+                    }
+            }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < MCHUNK; ++j) {
+                int m = m0 + j;
+                if (m < g.M) {
+                    size_t idx = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx;
+                    float base = 0.0f;
+                    if (zin) {
+                        base = zin[idx];
+                        if (gate && gate[idx] == 0.0f) base = 0.0f;
+                    }
+                    float u = fmaf(alpha, acc[j], base);
+                    out[idx] = tau ? cdl_shrink(u, tau[n * g.M + m]) : u;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthesis: v[c,d,y,x] = sum_{m,kd,ki,kj} zg[m,(d+pd-kd)/sd,(y+ph-ki)/sh,(x+pw-kj)/sw] * w[m,c,kd,ki,kj]
+// over taps whose numerators are multiples of the stride.  One workgroup = one (n, d, 16x16
+// tile of (y,x)); code channels are staged through LDS MCHUNK at a time (with the support
+// gate applied on the way in); up to 4 image channels accumulate per pass.
+__global__ __launch_bounds__(256) void k_synthesis(cdl_geom g, const float *__restrict__ z,
+                                                   const float *__restrict__ gate,
+                                                   const float *__restrict__ w, float alpha,
+                                                   const float *__restrict__ mask,
+                                                   const float *__restrict__ sub,
+                                                   float *__restrict__ out, int tilesX, int tilesY,
+                                                   int PZD, int PZH, int PZW)
+{
+    extern __shared__ float patch[];
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int d = b;
+    const int n = blockIdx.y;
+    const int ly = threadIdx.x / TILE, lx = threadIdx.x % TILE;
+    const int y = ty * TILE + ly, xo = tx * TILE + lx;
+    const int zd_lo = cdl_floordiv(d + g.pd - (g.Pd - 1), g.sd);
+    const int zy_lo = cdl_floordiv(ty * TILE + g.ph - (g.Ph - 1), g.sh);
+    const int zx_lo = cdl_floordiv(tx * TILE + g.pw - (g.Pw - 1), g.sw);
+    const int plane = PZH * PZW, pvol = PZD * plane;
+    const int taps = g.Pd * g.Ph * g.Pw;
+    const bool live = y < g.H && xo < g.W;
+
+    for (int c0 = 0; c0 < g.C; c0 += 4) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int m0 = 0; m0 < g.M; m0 += MCHUNK) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MCHUNK * pvol; i += 256) {
+                int px = i % PZW, r = i / PZW;
+                int py = r % PZH; r /= PZH;
+                int pd_ = r % PZD, mm = r / PZD;
+                int m = m0 + mm, zd = zd_lo + pd_, zy = zy_lo + py, zx = zx_lo + px;
+                float v = 0.0f;
+                if (m < g.M && zd >= 0 && zd < Dz && zy >= 0 && zy < Hz && zx >= 0 && zx < Wz) {
+                    size_t idx = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx;
+                    v = z[idx];
+                    if (gate && gate[idx] == 0.0f) v = 0.0f;
+                }
+                patch[i] = v;
+            }
+            __syncthreads();
+            for (int kd = 0; kd < g.Pd; ++kd) {
+                int td = d + g.pd - kd + g.sd * g.Pd;              // shifted positive
+                if (td % g.sd) continue;
+                int zd = td / g.sd - g.Pd - zd_lo;
+                for (int ki = 0; ki < g.Ph; ++ki) {
+                    int tyy = y + g.ph - ki + g.sh * g.Ph;
+                    if (tyy % g.sh) continue;
+                    int zy = tyy / g.sh - g.Ph - zy_lo;
+                    for (int kj = 0; kj < g.Pw; ++kj) {
+                        int txx = xo + g.pw - kj + g.sw * g.Pw;
+                        if (txx % g.sw) continue;
+                        int zx = txx / g.sw - g.Pw - zx_lo;
+                        int tap = (kd * g.Ph + ki) * g.Pw + kj;
+                        const float *pp = patch + (zd * PZH + zy) * PZW + zx;
+                        const int mlim = min(MCHUNK, g.M - m0);
+                        for (int mm = 0; mm < mlim; ++mm) {
+                            float v = pp[mm * pvol];
+                            const float *wr = w + ((size_t)(m0 + mm) * g.C + c0) * taps + tap;
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc)
+                                if (c0 + cc < g.C) acc[cc] = fmaf(v, wr[cc * taps], acc[cc]);
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                int c = c0 + cc;
+                if (c < g.C) {
+                    size_t idx = ((((size_t)n * g.C + c) * g.D + d) * g.H + y) * g.W + xo;
+                    float v = alpha * acc[cc];
+                    if (mask) v *= mask[idx];
+                    if (sub) v -= sub[idx];
+                    out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient: one workgroup per (m, c, kd, ki) filter row, Pw taps accumulated per
+// thread over a strided sweep of every code pixel; zeros of the (sparse / gated) code are
+// skipped.  Fixed reduction order -> deterministic.
+constexpr int PWMAX = 16;
+
+__global__ __launch_bounds__(256) void k_wgrad(cdl_geom g, const float *__restrict__ z,
+                                               const float *__restrict__ gate,
+                                               const float *__restrict__ x, float alpha,
+                                               float *__restrict__ dw)
+{
+    __shared__ float red[4][PWMAX];
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    const int m = blockIdx.x;
+    int r = blockIdx.y;
+    const int ki = r % g.Ph; r /= g.Ph;
+    const int kd = r % g.Pd;
+    const int c = r / g.Pd;
+    float acc[PWMAX];
+#pragma unroll
+    for (int j = 0; j < PWMAX; ++j) acc[j] = 0.0f;
+
+    const int rows = g.N * Dz * Hz;                  // (n, zd, zy) rows of the code
+    for (int row = threadIdx.x / 64; row < rows; row += 4) {      // one wave per code row
+        int zy = row % Hz, t = row / Hz;
+        int zd = t % Dz, n = t / Dz;
+        int d = zd * g.sd - g.pd + kd, y = zy * g.sh - g.ph + ki;
+        if (d < 0 || d >= g.D || y < 0 || y >= g.H) continue;
+        const float *zr = z + ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz;
+        const float *gr = gate ? gate + ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz : nullptr;
+        const float *xr = x + ((((size_t)n * g.C + c) * g.D + d) * g.H + y) * g.W;
+        for (int zx = threadIdx.x % 64; zx < Wz; zx += 64) {
+            float zv = zr[zx];
+            if (gr && gr[zx] == 0.0f) zv = 0.0f;
+            if (zv == 0.0f) continue;
+            int xb = zx * g.sw - g.pw;
+#pragma unroll
+            for (int kj = 0; kj < PWMAX; ++kj) {
+                int xx = xb + kj;
+                if (kj < g.Pw && xx >= 0 && xx < g.W) acc[kj] = fmaf(zv, xr[xx], acc[kj]);
+            }
+        }
+    }
+    const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
+#pragma unroll
+    for (int kj = 0; kj < PWMAX; ++kj) {
+        float v = acc[kj];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wv][kj] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < g.Pw) {
+        float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        dw[((((size_t)m * g.C + c) * g.Pd + kd) * g.Ph + ki) * g.Pw + threadIdx.x] = alpha * v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// threshold gradient, stage 1: s[n,m] = -sum_pix sign(zout) * g over the support of zout.
+__global__ __launch_bounds__(256) void k_tau_partial(const float *__restrict__ gup,
+                                                     const float *__restrict__ zout,
+                                                     float *__restrict__ s, size_t per_m)
+{
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * per_m;
+    float acc = 0.0f;
+    for (size_t i = threadIdx.x; i < per_m; i += 256) {
+        float zv = zout[base + i];
+        float gv = gup[base + i];
+        acc += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x % 64 == 0) red[threadIdx.x / 64] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) s[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// stage 2: dt0[m] = sum_n s[n,m]; dt1[m] = sum_n c[n] s[n,m]
+__global__ void k_tau_final(const float *__restrict__ s, const float *__restrict__ c,
+                            float *__restrict__ dt0, float *__restrict__ dt1, int N, int M)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        float v = s[n * M + m];
+        a0 += v;
+        if (c) a1 = fmaf(c[n], v, a1);
+    }
+    dt0[m] = a0;
+    dt1[m] = a1;
+}
+
+__global__ void k_shrink(const float *__restrict__ x, const float *__restrict__ tau,
+                         float *__restrict__ out, size_t total, size_t per_m)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = cdl_shrink(x[i], tau[i / per_m]);
+}
+
+__global__ void k_thresholds(const float *__restrict__ t, const float *__restrict__ c,
+                             float *__restrict__ tau, int K, int N, int M)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * N * M) return;
+    int m = i % M, n = (i / M) % N, k = i / (M * N);
+    float v = t[(k * 2 + 0) * M + m];
+    if (c) v = __fadd_rn(v, __fmul_rn(c[n], t[(k * 2 + 1) * M + m]));   // mul then add, as torch does
+    tau[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// pre / post processing
+__global__ __launch_bounds__(256) void k_sample_sums(const float *__restrict__ y,
+                                                     const float *__restrict__ mask,
+                                                     float *__restrict__ mean, size_t per_n)
+{
+    __shared__ double red[2][4];
+    const size_t base = (size_t)blockIdx.x * per_n;
+    double sy = 0.0, sm = 0.0;
+    for (size_t i = threadIdx.x; i < per_n; i += 256) {
+        sy += y[base + i];
+        if (mask) sm += mask[base + i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sy += __shfl_down(sy, off, 64);
+        sm += __shfl_down(sm, off, 64);
+    }
+    if (threadIdx.x % 64 == 0) { red[0][threadIdx.x / 64] = sy; red[1][threadIdx.x / 64] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ty = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        double tm = mask ? (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) : (double)per_n;
+        mean[blockIdx.x] = (float)(ty / tm);
+    }
+}
+
+__device__ __forceinline__ int reflect(int q, int lo, int L)
+{
+    int u = q - lo;
+    if (u < 0) u = -u;
+    if (u >= L) u = 2 * (L - 1) - u;
+    return u;
+}
+
+__global__ void k_pad_center(const float *__restrict__ y, const float *__restrict__ mask,
+                             const float *__restrict__ mean, float *__restrict__ yp,
+                             float *__restrict__ mask_p, int N, int C, int D, int H, int W,
+                             int d_lo, int h_lo, int w_lo, int Dp, int Hp, int Wp)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)N * C * Dp * Hp * Wp;
+    if (i >= total) return;
+    int xq = i % Wp; size_t r = i / Wp;
+    int yq = r % Hp; r /= Hp;
+    int dq = r % Dp; r /= Dp;
+    int c = r % C, n = r / C;
+    size_t src = ((((size_t)n * C + c) * D + reflect(dq, d_lo, D)) * H + reflect(yq, h_lo, H)) * W +
+                 reflect(xq, w_lo, W);
+    float v = y[src] - mean[n];
+    if (mask) {
+        float mv = mask[src];
+        v *= mv;
+        mask_p[i] = mv;
+    }
+    yp[i] = v;
+}
+
+__global__ void k_crop_add(const float *__restrict__ xp, const float *__restrict__ mean,
+                           float *__restrict__ xhat, int N, int C, int D, int H, int W,
+                           int d_lo, int h_lo, int w_lo, int Dp, int Hp, int Wp)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)N * C * D * H * W;
+    if (i >= total) return;
+    int xq = i % W; size_t r = i / W;
+    int yq = r % H; r /= H;
+    int dq = r % D; r /= D;
+    int c = r % C, n = r / C;
+    size_t src = ((((size_t)n * C + c) * Dp + dq + d_lo) * Hp + yq + h_lo) * Wp + xq + w_lo;
+    xhat[i] = xp[src] + mean[n];
+}
+
+__global__ void k_embed(const float *__restrict__ gx, float *__restrict__ gxp, int N, int C, int D,
+                        int H, int W, int d_lo, int h_lo, int w_lo, int Dp, int Hp, int Wp)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)N * C * Dp * Hp * Wp;
+    if (i >= total) return;
+    int xq = (int)(i % Wp) - w_lo; size_t r = i / Wp;
+    int yq = (int)(r % Hp) - h_lo; r /= Hp;
+    int dq = (int)(r % Dp) - d_lo; r /= Dp;
+    float v = 0.0f;
+    if (xq >= 0 && xq < W && yq >= 0 && yq < H && dq >= 0 && dq < D)
+        v = gx[((r * D + dq) * H + yq) * W + xq];            // r = n*C + c
+    gxp[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// unit-ball projection: one wave per filter
+__global__ __launch_bounds__(64) void k_project(float *__restrict__ w, int flen)
+{
+    float *f = w + (size_t)blockIdx.x * flen;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < flen; i += 64) ss = fmaf(f[i], f[i], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    float scale = fminf(1.0f / sqrtf(ss), 1.0f);
+    if (scale < 1.0f)
+        for (int i = threadIdx.x; i < flen; i += 64) f[i] *= scale;
+}
+
+// ------------------------------------------------------------------------------------------
+// Gabor dictionary synthesis and its adjoint
+__global__ void k_gabor(const float *__restrict__ alpha, const float *__restrict__ a,
+                        const float *__restrict__ w0, const float *__restrict__ psi,
+                        float *__restrict__ w, int order, int MC, int P, float sgn)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MC * P * P) return;
+    int kj = i % P, ki = (i / P) % P, mc = i / (P * P);
+    float gy = (float)ki - 0.5f * (P - 1), gx = (float)kj - 0.5f * (P - 1);
+    float acc = 0.0f;
+    for (int o = 0; o < order; ++o) {
+        int q = o * MC + mc;
+        float e0 = a[2 * q] * gy, e1 = a[2 * q + 1] * gx;
+        float env = expf(-(e0 * e0 + e1 * e1));
+        float ph = sgn * w0[2 * q] * gy + sgn * w0[2 * q + 1] * gx + sgn * psi[q];
+        acc += alpha[q] * (env * cosf(ph));
+    }
+    w[i] = acc;
+}
+
+__global__ void k_gabor_bwd(const float *__restrict__ alpha, const float *__restrict__ a,
+                            const float *__restrict__ w0, const float *__restrict__ psi,
+                            const float *__restrict__ dw, float *__restrict__ dalpha,
+                            float *__restrict__ da, float *__restrict__ dw0,
+                            float *__restrict__ dpsi, int order, int MC, int P, float sgn)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= order * MC) return;
+    int mc = q % MC;
+    float al = alpha[q], a0 = a[2 * q], a1 = a[2 * q + 1];
+    float f0 = sgn * w0[2 * q], f1 = sgn * w0[2 * q + 1], ps = sgn * psi[q];
+    float g_al = 0, g_a0 = 0, g_a1 = 0, g_f0 = 0, g_f1 = 0, g_ps = 0;
+    for (int ki = 0; ki < P; ++ki)
+        for (int kj = 0; kj < P; ++kj) {
+            float gy = (float)ki - 0.5f * (P - 1), gx = (float)kj - 0.5f * (P - 1);
+            float e0 = a0 * gy, e1 = a1 * gx;
+            float env = expf(-(e0 * e0 + e1 * e1));
+            float ph = f0 * gy + f1 * gx + ps;
+            float cs = cosf(ph), sn = sinf(ph);
+            float up = dw[(size_t)mc * P * P + ki * P + kj];
+            g_al += up * env * cs;
+            float de = up * al * cs * env;            // d/d(env exponent) carrier
+            g_a0 += de * (-2.0f * a0 * gy * gy);
+            g_a1 += de * (-2.0f * a1 * gx * gx);
+            float dp = -up * al * env * sn;           // d/d(phase)
+            g_f0 += dp * sgn * gy;
+            g_f1 += dp * sgn * gx;
+            g_ps += dp * sgn;
+        }
+    dalpha[q] = g_al;
+    da[2 * q] = g_a0; da[2 * q + 1] = g_a1;
+    dw0[2 * q] = g_f0; dw0[2 * q + 1] = g_f1;
+    dpsi[q] = g_ps;
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+const char *cdl_version(void) { return "cdlnet_hip 0.1 (gfx950)"; }
+
+int cdl_preprocess(const float *y, const float *mask, float *yp, float *mask_p, float *mean,
+                   int N, int C, int D, int H, int W, const int pads[6], void *stream)
+{
+    if (!y || !yp || !mean || !pads || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return CDL_EINVAL;
+    if ((mask == nullptr) != (mask_p == nullptr)) return CDL_EINVAL;
+    for (int i = 0; i < 6; ++i) if (pads[i] < 0) return CDL_EINVAL;
+    // reflect padding needs pad < extent on that axis
+    const int ext[3] = {D, H, W};
+    for (int i = 0; i < 6; ++i) if (pads[i] && pads[i] >= ext[i / 2]) return CDL_EINVAL;
+    size_t per_n = (size_t)C * D * H * W;
+    k_sample_sums<<<N, 256, 0, S(stream)>>>(y, mask, mean, per_n);
+    CDL_LAUNCH_CHECK();
+    int Dp = D + pads[0] + pads[1], Hp = H + pads[2] + pads[3], Wp = W + pads[4] + pads[5];
+    size_t total = (size_t)N * C * Dp * Hp * Wp;
+    k_pad_center<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(
+        y, mask, mean, yp, mask_p, N, C, D, H, W, pads[0], pads[2], pads[4], Dp, Hp, Wp);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_postprocess(const float *xp, const float *mean, float *xhat, int N, int C, int D, int H,
+                    int W, const int pads[6], void *stream)
+{
+    if (!xp || !mean || !xhat || !pads || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return CDL_EINVAL;
+    int Dp = D + pads[0] + pads[1], Hp = H + pads[2] + pads[3], Wp = W + pads[4] + pads[5];
+    size_t total = (size_t)N * C * D * H * W;
+    k_crop_add<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(
+        xp, mean, xhat, N, C, D, H, W, pads[0], pads[2], pads[4], Dp, Hp, Wp);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_postprocess_bwd(const float *gxhat, float *gxp, int N, int C, int D, int H, int W,
+                        const int pads[6], void *stream)
+{
+    if (!gxhat || !gxp || !pads || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return CDL_EINVAL;
+    int Dp = D + pads[0] + pads[1], Hp = H + pads[2] + pads[3], Wp = W + pads[4] + pads[5];
+    size_t total = (size_t)N * C * Dp * Hp * Wp;
+    k_embed<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(gxhat, gxp, N, C, D, H, W, pads[0],
+                                                                  pads[2], pads[4], Dp, Hp, Wp);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_thresholds(const float *t, const float *c, float *tau, int K, int N, int M, void *stream)
+{
+    if (!t || !tau || K <= 0 || N <= 0 || M <= 0) return CDL_EINVAL;
+    int total = K * N * M;
+    k_thresholds<<<(total + 255) / 256, 256, 0, S(stream)>>>(t, c, tau, K, N, M);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_shrink(const float *x, const float *tau, float *out, int rows, size_t per_m, void *stream)
+{
+    if (!x || !tau || !out || rows <= 0 || per_m == 0) return CDL_EINVAL;
+    size_t total = (size_t)rows * per_m;
+    k_shrink<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(x, tau, out, total, per_m);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                 const float *gate, const float *tau, float *out, void *stream)
+{
+    if (!cdl_geom_ok(g) || !x || !w || !out) return CDL_EINVAL;
+    if (out == zin) return CDL_EINVAL;
+    if (gate && !zin) return CDL_EINVAL;
+    const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    const int tilesX = (Wz + TILE - 1) / TILE, tilesY = (Hz + TILE - 1) / TILE;
+    const int PH = (TILE - 1) * g->sh + g->Ph, PW = (TILE - 1) * g->sw + g->Pw;
+    size_t lds = (size_t)g->C * g->Pd * PH * PW * sizeof(float);
+    if (lds > 160 * 1024) return CDL_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_analysis,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+    }
+    dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N);
+    k_analysis<<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                  const float *mask, const float *sub, float *out, void *stream)
+{
+    if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
+    const int tilesX = (g->W + TILE - 1) / TILE, tilesY = (g->H + TILE - 1) / TILE;
+    // upper bound on the code patch a 16x16 output tile (one d) can touch, per axis
+    const int PZD = (g->Pd - 1) / g->sd + 2;
+    const int PZH = (TILE - 1 + g->Ph - 1) / g->sh + 2;
+    const int PZW = (TILE - 1 + g->Pw - 1) / g->sw + 2;
+    size_t lds = (size_t)MCHUNK * PZD * PZH * PZW * sizeof(float);
+    if (lds > 160 * 1024) return CDL_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_synthesis,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+    }
+    dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N);
+    k_synthesis<<<grid, 256, lds, S(stream)>>>(*g, z, gate, w, alpha, mask, sub, out, tilesX, tilesY,
+                                                PZD, PZH, PZW);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
+              float *dw, void *stream)
+{
+    if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
+    if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
+    dim3 grid((unsigned)g->M, (unsigned)(g->C * g->Pd * g->Ph));
+    k_wgrad<<<grid, 256, 0, S(stream)>>>(*g, z, gate, x, alpha, dw);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c, float *dt0,
+                 float *dt1, float *scratch, void *stream)
+{
+    if (!cdl_geom_ok(g) || !gup || !zout || !dt0 || !dt1 || !scratch) return CDL_EINVAL;
+    size_t per_m = (size_t)(g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
+    k_tau_partial<<<(unsigned)(g->N * g->M), 256, 0, S(stream)>>>(gup, zout, scratch, per_m);
+    CDL_LAUNCH_CHECK();
+    k_tau_final<<<(g->M + 63) / 64, 64, 0, S(stream)>>>(scratch, c, dt0, dt1, g->N, g->M);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_project_filters(float *w, int nfilters, int flen, void *stream)
+{
+    if (!w || nfilters <= 0 || flen <= 0) return CDL_EINVAL;
+    k_project<<<nfilters, 64, 0, S(stream)>>>(w, flen);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_gabor_filters(const float *alpha, const float *a, const float *w0, const float *psi, float *w,
+                      int order, int M, int C, int P, int transpose, void *stream)
+{
+    if (!alpha || !a || !w0 || !psi || !w || order <= 0 || M <= 0 || C <= 0 || P <= 0) return CDL_EINVAL;
+    int total = M * C * P * P;
+    k_gabor<<<(total + 255) / 256, 256, 0, S(stream)>>>(alpha, a, w0, psi, w, order, M * C, P,
+                                                        transpose ? -1.0f : 1.0f);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, const float *psi,
+                          const float *dw, float *dalpha, float *da, float *dw0, float *dpsi,
+                          int order, int M, int C, int P, int transpose, void *stream)
+{
+    if (!alpha || !a || !w0 || !psi || !dw || !dalpha || !da || !dw0 || !dpsi) return CDL_EINVAL;
+    if (order <= 0 || M <= 0 || C <= 0 || P <= 0) return CDL_EINVAL;
+    int total = order * M * C;
+    k_gabor_bwd<<<(total + 63) / 64, 64, 0, S(stream)>>>(alpha, a, w0, psi, dw, dalpha, da, dw0, dpsi,
+                                                         order, M * C, P, transpose ? -1.0f : 1.0f);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+"""Drop-in modules for the reference's `model/net.py` hot path.
+
+Same constructor signatures, attribute names (`A`, `B`, `D`, `t`, `g`, `K`, `M`, `P`, `s`, `t0`,
+`adaptive`), `state_dict` keys and `forward(y, sigma=None, mask=1) -> (xhat, z)` contract as
+`CDLNet` (net.py:16-104), `CDLNetVideo` (net.py:121-227) and `GDLNet` (net.py:569-687); the K
+iterations run in hand-written HIP kernels (libcdlnet_hip.so) instead of ATen convolutions.
+
+The filter containers subclass `nn.Conv{2,3}d` / `nn.ConvTranspose{2,3}d` purely as parameter
+holders: identical `weight` shapes and state_dict keys, and -- because their default
+initialisers draw from the global RNG exactly like the reference's -- `torch.manual_seed(s);
+CDLNet(...)` yields the reference's weights bit for bit.  Their `forward` is overridden to
+call the HIP operators; no ATen convolution runs on the device.
+"""
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import loop, ops
+from .gabor import ConvAdjoint2dGabor, gabor_kernel_cpu
+from .solvers import gram_operator, power_method
+
+
+def ST(x, t):
+    """Shrinkage-thresholding sign(x)*relu(|x|-t) (net.py:11-14) on the device.
+
+    Stand-alone form for callers of the reference's helper (t broadcastable to
+    (N, M, 1, ..)); inside the nets it is fused into the analysis kernel's epilogue.
+    """
+    N, M = x.shape[:2]
+    tau = torch.as_tensor(t, dtype=torch.float32, device=x.device)
+    while tau.dim() < x.dim():
+        tau = tau.unsqueeze(0)
+    tau = torch.broadcast_to(tau, (N, M) + (1,) * (x.dim() - 2)).reshape(N, M).contiguous()
+    return ops.shrink(x, tau)
+
+
+# ------------------------------------------------------------------------------------------ banks
+class _Analysis2d(nn.Conv2d):
+    def forward(self, x):
+        g = ops.Geometry.make(x.shape[0], self.in_channels, self.out_channels, x.shape[2:],
+                              self.kernel_size, self.padding, self.stride[0])
+        return ops.analysis(g, x, self.weight.detach())
+
+
+class _Synthesis2d(nn.ConvTranspose2d):
+    def forward(self, z):
+        sp = tuple(d * self.stride[0] for d in z.shape[2:])
+        g = ops.Geometry.make(z.shape[0], self.out_channels, self.in_channels, sp,
+                              self.kernel_size, self.padding, self.stride[0])
+        return ops.synthesis(g, z, self.weight.detach())
+
+
+class _Analysis3d(nn.Conv3d):
+    def forward(self, x):
+        g = ops.Geometry.make(x.shape[0], self.in_channels, self.out_channels, x.shape[2:],
+                              self.kernel_size, self.padding, self.stride[0])
+        return ops.analysis(g, x, self.weight.detach())
+
+
+class _Synthesis3d(nn.ConvTranspose3d):
+    def forward(self, z):
+        sp = tuple(d * self.stride[0] for d in z.shape[2:])
+        g = ops.Geometry.make(z.shape[0], self.out_channels, self.in_channels, sp,
+                              self.kernel_size, self.padding, self.stride[0])
+        return ops.synthesis(g, z, self.weight.detach())
+
+
+def _noise_scale(sigma, adaptive, N, device):
+    """c = sigma/255 per sample as an (N,) tensor, or None for c = 0 (net.py:82)."""
+    if sigma is None or not adaptive:
+        return None
+    if torch.is_tensor(sigma):
+        c = sigma.to(device=device, dtype=torch.float32).reshape(-1) / 255.0
+        if c.numel() == 1:
+            c = c.expand(N)
+        if c.numel() != N:
+            raise ValueError("sigma must be a scalar or hold one value per sample")
+        return c.contiguous()
+    return torch.full((N,), float(sigma) / 255.0, device=device, dtype=torch.float32)
+
+
+def _mask_tensor(mask, y):
+    if torch.is_tensor(mask):
+        return torch.broadcast_to(mask.to(dtype=torch.float32), y.shape).contiguous()
+    if mask is None or mask == 1:
+        return None
+    raise ValueError("mask must be 1 (no mask) or a tensor shaped like y")
+
+
+class _ISTANet(nn.Module):
+    """Shared forward / generator plumbing."""
+
+    def _filters(self):
+        A = [m.weight for m in self.A]
+        B = [m.weight for m in self.B]
+        return A, B
+
+    def _run(self, y, sigma, mask, all_codes):
+        if not y.is_cuda:
+            raise RuntimeError(
+                f"{type(self).__name__}.forward: input is on {y.device}. This package has no CPU "
+                "compute path; the iterations run in HIP kernels on a ROCm device.")
+        y = y.to(torch.float32)
+        A, B = self._filters()
+        c = _noise_scale(sigma, self.adaptive, y.shape[0], y.device)
+        return loop.run(y, _mask_tensor(mask, y), c, self.t, A, B, self.s, all_codes)
+
+    def forward(self, y, sigma=None, mask=1):
+        """LISTA + D with noise-adaptive thresholds: returns (xhat, z_K)."""
+        xhat, z = self._run(y, sigma, mask, False)
+        return xhat, z
+
+    def forward_generator(self, y, sigma=None, mask=1):
+        """Yields z_1..z_K, then xhat (net.py:94-104, 214-227)."""
+        outs = self._run(y, sigma, mask, True)
+        xhat, zK, earlier = outs[0], outs[1], outs[2:]
+        for z in earlier:
+            yield z
+        yield zK
+        yield xhat
+
+
+# ------------------------------------------------------------------------------------------ 2-D
+class CDLNet(_ISTANet):
+    """Convolutional Dictionary Learning Network (2-D; JDD = C=3 + Bayer mask)."""
+
+    def __init__(self, K=3, M=64, P=7, s=1, C=1, t0=0, adaptive=False, init=True):
+        super().__init__()
+        if P % 2 == 0:
+            raise ValueError("P must be odd (the reference's conv / conv-transpose pair needs it)")
+        self.A = nn.ModuleList([_Analysis2d(C, M, P, stride=s, padding=(P - 1) // 2, bias=False)
+                                for _ in range(K)])
+        self.B = nn.ModuleList([_Synthesis2d(M, C, P, stride=s, padding=(P - 1) // 2,
+                                             output_padding=s - 1, bias=False) for _ in range(K)])
+        self.D = self.B[0]
+        self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self.g = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))       # unused, kept for checkpoints
+        W = torch.randn(M, C, P, P)
+        for k in range(K):
+            self.A[k].weight.data = W.clone()
+            self.B[k].weight.data = W.clone()
+        if init:
+            print("Running power-method on initial dictionary...")
+            with torch.no_grad():
+                op = gram_operator(self.A[0].weight, self.D.weight, s, (P - 1) // 2)
+                L = power_method(op, torch.rand(1, C, 128, 128), num_iter=200, verbose=False)[0]
+            print(f"Done. L={L:.3e}.")
+            if L < 0:
+                print("STOP: something is very very wrong...")
+                sys.exit()
+            for k in range(K):
+                self.A[k].weight.data /= np.sqrt(L)
+                self.B[k].weight.data /= np.sqrt(L)
+        self.K, self.M, self.P, self.s, self.t0, self.adaptive = K, M, P, s, t0, adaptive
+
+    @torch.no_grad()
+    def project(self):
+        """l2-ball projection of every filter, R+ projection of the thresholds (net.py:66-74)."""
+        self.t.clamp_(0.0)
+        for k in range(self.K):
+            ops.project_filters_(self.A[k].weight.data)
+            ops.project_filters_(self.B[k].weight.data)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts upstream CDLNet-OJSP checkpoints that predate the unused `g` parameter."""
+        if "g" not in state_dict and "t" in state_dict:
+            state_dict = dict(state_dict)
+            state_dict["g"] = self.g.detach().clone()
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+
+# ------------------------------------------------------------------------------------------ 3-D
+class CDLNetVideo(_ISTANet):
+    """3-D (video / volume) twin; `P` is (kD, kH, kW) or an int (cube)."""
+
+    def __init__(self, K=3, M=64, P=(7, 7, 5), s=1, C=1, t0=0, adaptive=False, depth=3, init=True,
+                 residual=False):
+        super().__init__()
+        if residual:
+            raise NotImplementedError("residual=True (ResidualBlock, net.py:105-120) is outside the "
+                                      "hot path this package replaces; no shipped config enables it")
+        if isinstance(P, int):
+            P = (P, P, P)
+        P = tuple(int(p) for p in P)
+        if any(p % 2 == 0 for p in P):
+            raise ValueError("every filter extent must be odd")
+        pad = tuple(p // 2 for p in P)
+        self.A = nn.ModuleList([_Analysis3d(C, M, P, stride=s, padding=pad, bias=False)
+                                for _ in range(K)])
+        self.B = nn.ModuleList([_Synthesis3d(M, C, P, stride=s, padding=pad, output_padding=s - 1,
+                                             bias=False) for _ in range(K)])
+        self.D = self.B[0]
+        self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1, 1))
+        self.residual = False
+        W = torch.randn(M, C, *P)
+        for k in range(K):
+            self.A[k].weight.data = W.clone()
+            self.B[k].weight.data = W.clone()
+        if init:
+            print("Running power-method on initial dictionary...")
+            with torch.no_grad():
+                op = gram_operator(self.A[0].weight, self.D.weight, s, pad)
+                L = power_method(op, torch.rand(1, C, depth, 128, 128), num_iter=200, verbose=False)[0]
+            print(f"Done. L={L:.3e}.")
+            if L < 0:
+                print("STOP: something is very very wrong...")
+                sys.exit()
+            for k in range(K):
+                self.A[k].weight.data /= np.sqrt(L)
+                self.B[k].weight.data /= np.sqrt(L)
+        self.K, self.M, self.P, self.s, self.t0, self.adaptive = K, M, P, s, t0, adaptive
+
+    @torch.no_grad()
+    def project(self):
+        """net.py:184-190.  (The reference's own call raises on torch >= 2: `torch.norm` with a
+        3-axis `dim`; this does what it evidently means -- the l2 norm over the filter volume.)"""
+        self.t.clamp_(0.0)
+        for k in range(self.K):
+            ops.project_filters_(self.A[k].weight.data)
+            ops.project_filters_(self.B[k].weight.data)
+
+
+# ------------------------------------------------------------------------------------------ Gabor
+class GDLNet(_ISTANet):
+    """Gabor Dictionary Learning Network: same loop, filters synthesised from Gabor parameters."""
+
+    def __init__(self, K=3, M=64, P=7, s=1, C=1, t0=0, order=1, adaptive=False, shared="", init=True):
+        super().__init__()
+        self.A = nn.ModuleList([ConvAdjoint2dGabor(M, C, P, stride=s, order=order) for _ in range(K)])
+        self.B = nn.ModuleList([ConvAdjoint2dGabor(M, C, P, stride=s, order=order) for _ in range(K)])
+        self.D = self.B[0]
+        self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        alpha = torch.randn(order, M, C, 1, 1)
+        a = torch.randn(order, M, C, 2)
+        w0 = torch.randn(order, M, C, 2)
+        psi = torch.randn(order, M, C)
+        for k in range(K):
+            for bank in (self.A[k], self.B[k]):
+                bank.alpha.data = alpha.clone()
+                bank.a.data = a.clone()
+                bank.w0.data = w0.clone()
+                bank.psi.data = psi.clone()
+            if k > 0:                                   # parameter sharing by aliasing (net.py:607-622)
+                if "alpha" in shared:
+                    self.A[k].alpha = self.A[0].alpha
+                    if k > 1:                           # never share the scale with D = B[0]
+                        self.B[k].alpha = self.B[1].alpha
+                if "a_" in shared:
+                    self.A[k].a, self.B[k].a = self.A[0].a, self.B[0].a
+                if "w0" in shared:
+                    self.A[k].w0, self.B[k].w0 = self.A[0].w0, self.B[0].w0
+                if "psi" in shared:
+                    self.A[k].psi, self.B[k].psi = self.A[0].psi, self.B[0].psi
+        if init:
+            print("Running power-method on initial dictionary...")
+            with torch.no_grad():
+                wa = gabor_kernel_cpu(self.A[0].alpha, self.A[0].a, self.A[0].w0, self.A[0].psi, P, True)
+                wd = gabor_kernel_cpu(self.D.alpha, self.D.a, self.D.w0, self.D.psi, P, False)
+                L = power_method(gram_operator(wa, wd, s, (P - 1) // 2), torch.rand(1, C, 128, 128),
+                                 num_iter=200, verbose=False)[0]
+            print(f"Done. L={L:.3e}.")
+            if L < 0:
+                print("STOP: something is very very wrong...")
+                sys.exit()
+            for k in range(K):                          # net.py:637-642
+                self.A[k].alpha.data /= np.sqrt(L)
+                self.B[k].alpha.data /= np.sqrt(L)
+                if "alpha" in shared:
+                    self.B[1].alpha.data /= np.sqrt(L)
+                    break
+        self.K, self.M, self.P, self.s, self.t0 = K, M, P, s, t0
+        self.order, self.adaptive = order, adaptive
+
+    def _filters(self):
+        A = [m.get_filter(transpose=True) for m in self.A]
+        B = [m.get_filter() for m in self.B]
+        return A, B
+
+    @torch.no_grad()
+    def project(self):
+        self.t.clamp_(0.0)

@@ -1,0 +1,270 @@
+"""Tensor-level wrappers over the C ABI (include/cdlnet_hip.h).
+
+PyTorch supplies device memory and the stream; every operation here is a call into
+libcdlnet_hip.so.  Inputs must be CUDA (ROCm) fp32 tensors -- there is no CPU path.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: cdlnet-video_amd computes only through its HIP kernels "
+            "(libcdlnet_hip.so) on a ROCm device; move the module and inputs to 'cuda'.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _opt(t, name):
+    return None if t is None else _dev(t, name)
+
+
+def _three(v, fill):
+    v = [int(x) for x in v]
+    return [fill] * (3 - len(v)) + v
+
+
+@dataclass(frozen=True)
+class Geometry:
+    """Operator geometry in the 3-D convention of `cdl_geom` (2-D: leading axis is 1)."""
+    N: int
+    C: int
+    M: int
+    dims: Tuple[int, int, int]        # padded image extents D,H,W
+    P: Tuple[int, int, int]
+    pad: Tuple[int, int, int]
+    stride: Tuple[int, int, int]
+    ndim: int                         # 2 or 3: how tensors are shaped on the Python side
+
+    @staticmethod
+    def make(N, C, M, spatial, P, pad, stride):
+        nd = len(spatial)
+        stride = [stride] * nd if isinstance(stride, int) else list(stride)
+        g = Geometry(int(N), int(C), int(M), tuple(_three(spatial, 1)), tuple(_three(P, 1)),
+                     tuple(_three(pad, 0)), tuple(_three(stride, 1)), nd)
+        for d, s in zip(g.dims, g.stride):
+            if d % s:
+                raise ValueError(f"image extent {d} is not a multiple of stride {s}")
+        for p, q in zip(g.P, g.pad):
+            if p % 2 == 0 or q != p // 2:
+                raise ValueError("filters must have odd extent with padding P//2 "
+                                 "(the reference's conv/conv-transpose pair only closes for odd P)")
+        return g
+
+    @property
+    def code_spatial(self):
+        return tuple(d // s for d, s in zip(self.dims, self.stride))[3 - self.ndim:]
+
+    @property
+    def image_spatial(self):
+        return self.dims[3 - self.ndim:]
+
+    def c_struct(self):
+        return _lib.Geom(self.N, self.C, self.M, *self.dims, *self.P, *self.pad, *self.stride)
+
+    def code_shape(self):
+        return (self.N, self.M) + self.code_spatial
+
+    def image_shape(self):
+        return (self.N, self.C) + self.image_spatial
+
+    def filter_shape(self):
+        return (self.M, self.C) + self.P[3 - self.ndim:]
+
+
+def _pads6(pads, ndim):
+    """F.pad-ordered (last dim first) pads -> {d_lo,d_hi,h_lo,h_hi,w_lo,w_hi} int array."""
+    per_axis = [(pads[2 * i], pads[2 * i + 1]) for i in range(ndim)][::-1]   # first spatial dim first
+    flat = [0, 0] * (3 - ndim) + [v for lo_hi in per_axis for v in lo_hi]
+    return (ctypes.c_int * 6)(*flat)
+
+
+def split_pad(length, s):
+    """(before, after) making `length` a multiple of s, floor/ceil split (model/utils.py:35-44)."""
+    rem = length % s
+    if rem == 0:
+        return (0, 0)
+    extra = s - rem
+    return (extra // 2, extra - extra // 2)
+
+
+def stride_pads(spatial, s):
+    """F.pad-ordered tuple (model/utils.py:46-51, 103-111)."""
+    out = []
+    for length in reversed(tuple(spatial)):
+        out.extend(split_pad(int(length), s))
+    return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------
+def preprocess(y, s, mask=None):
+    """model/utils.py:5-22 / 70-87 on the device: returns (yp, mean(N,), pads, mask_p)."""
+    y = _dev(y, "y")
+    mask = _opt(mask, "mask")
+    if mask is not None and mask.shape != y.shape:
+        raise ValueError("mask must have the shape of y")
+    nd = y.dim() - 2
+    if nd not in (2, 3):
+        raise ValueError("expected (N,C,H,W) or (N,C,D,H,W)")
+    N, C = y.shape[:2]
+    sp = _three(y.shape[2:], 1)
+    pads = stride_pads(y.shape[2:], s)
+    p6 = _pads6(pads, nd)
+    padded = tuple(int(d) + p6[2 * i] + p6[2 * i + 1] for i, d in enumerate(sp))[3 - nd:]
+    yp = torch.empty((N, C) + padded, device=y.device, dtype=torch.float32)
+    mask_p = torch.empty_like(yp) if mask is not None else None
+    mean = torch.empty(N, device=y.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_preprocess(_ptr(y), _ptr(mask), _ptr(yp), _ptr(mask_p), _ptr(mean),
+                                   N, C, *sp, p6, _stream())
+    _lib.check(rc, "cdl_preprocess")
+    return yp, mean, pads, mask_p
+
+
+def postprocess(xp, mean, pads):
+    """model/utils.py:24-33 / 89-101: crop the stride padding and add the mean back."""
+    xp = _dev(xp, "xp")
+    nd = xp.dim() - 2
+    N, C = xp.shape[:2]
+    p6 = _pads6(pads, nd)
+    spp = _three(xp.shape[2:], 1)
+    sp = [spp[i] - p6[2 * i] - p6[2 * i + 1] for i in range(3)]
+    out = torch.empty((N, C) + tuple(sp[3 - nd:]), device=xp.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_postprocess(_ptr(xp), _ptr(mean), _ptr(out), N, C, *sp, p6, _stream())
+    _lib.check(rc, "cdl_postprocess")
+    return out
+
+
+def postprocess_bwd(gxhat, pads):
+    gxhat = _dev(gxhat, "grad_xhat")
+    nd = gxhat.dim() - 2
+    N, C = gxhat.shape[:2]
+    p6 = _pads6(pads, nd)
+    sp = _three(gxhat.shape[2:], 1)
+    spp = [sp[i] + p6[2 * i] + p6[2 * i + 1] for i in range(3)]
+    out = torch.empty((N, C) + tuple(spp[3 - nd:]), device=gxhat.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_postprocess_bwd(_ptr(gxhat), _ptr(out), N, C, *sp, p6, _stream())
+    _lib.check(rc, "cdl_postprocess_bwd")
+    return out
+
+
+def thresholds(t, c, N):
+    """tau (K,N,M) = t[k,0] + c[n]*t[k,1]; t is the (K,2,M,1,1[,1]) parameter."""
+    t = _dev(t, "t")
+    K, two, M = t.shape[:3]
+    c = _opt(c, "c")
+    tau = torch.empty((K, N, M), device=t.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_thresholds(_ptr(t), _ptr(c), _ptr(tau), K, N, M, _stream())
+    _lib.check(rc, "cdl_thresholds")
+    return tau
+
+
+def shrink(x, tau):
+    """ST(x, tau) with tau (N,M) broadcast over the spatial axes (net.py:11-14)."""
+    x, tau = _dev(x, "x"), _dev(tau, "tau")
+    rows = x.shape[0] * x.shape[1]
+    assert tau.numel() == rows
+    out = torch.empty_like(x)
+    rc = _lib.lib().cdl_shrink(_ptr(x), _ptr(tau), _ptr(out), rows, x.numel() // rows, _stream())
+    _lib.check(rc, "cdl_shrink")
+    return out
+
+
+def analysis(g: Geometry, x, w, alpha=1.0, zin=None, gate=None, tau=None, out=None):
+    x, w = _dev(x, "x"), _dev(w, "w")
+    zin, gate, tau = _opt(zin, "zin"), _opt(gate, "gate"), _opt(tau, "tau")
+    assert tuple(x.shape) == g.image_shape(), (x.shape, g.image_shape())
+    assert tuple(w.shape) == g.filter_shape(), (w.shape, g.filter_shape())
+    if out is None:
+        out = torch.empty(g.code_shape(), device=x.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_analysis(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin),
+                                 _ptr(gate), _ptr(tau), _ptr(out), _stream())
+    _lib.check(rc, "cdl_analysis")
+    return out
+
+
+def synthesis(g: Geometry, z, w, alpha=1.0, gate=None, mask=None, sub=None, out=None):
+    z, w = _dev(z, "z"), _dev(w, "w")
+    gate, mask, sub = _opt(gate, "gate"), _opt(mask, "mask"), _opt(sub, "sub")
+    assert tuple(z.shape) == g.code_shape(), (z.shape, g.code_shape())
+    assert tuple(w.shape) == g.filter_shape(), (w.shape, g.filter_shape())
+    if out is None:
+        out = torch.empty(g.image_shape(), device=z.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_synthesis(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(w), float(alpha),
+                                  _ptr(mask), _ptr(sub), _ptr(out), _stream())
+    _lib.check(rc, "cdl_synthesis")
+    return out
+
+
+def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):
+    z, x, gate = _dev(z, "z"), _dev(x, "x"), _opt(gate, "gate")
+    dw = torch.empty(g.filter_shape(), device=z.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_wgrad(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(x), float(alpha), _ptr(dw),
+                              _stream())
+    _lib.check(rc, "cdl_wgrad")
+    return dw
+
+
+def tau_grad(g: Geometry, gup, zout, c, dt_k):
+    """Writes the (2,M) slice `dt_k` of the threshold gradient for one iteration."""
+    gup, zout, c = _dev(gup, "g"), _dev(zout, "zout"), _opt(c, "c")
+    scratch = torch.empty(g.N * g.M, device=gup.device, dtype=torch.float32)
+    assert dt_k.is_contiguous() and dt_k.numel() == 2 * g.M
+    gs = g.c_struct()
+    base = dt_k.data_ptr()
+    rc = _lib.lib().cdl_tau_grad(ctypes.byref(gs), _ptr(gup), _ptr(zout), _ptr(c),
+                                 ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * g.M),
+                                 _ptr(scratch), _stream())
+    _lib.check(rc, "cdl_tau_grad")
+
+
+def project_filters_(w):
+    """In-place unit-ball projection of every (m,c) filter of w (M,C,*P)."""
+    if not w.is_cuda:
+        raise RuntimeError("project(): parameters must live on the ROCm device (no CPU path)")
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    nf = w.shape[0] * w.shape[1]
+    rc = _lib.lib().cdl_project_filters(_ptr(w), nf, w.numel() // nf, _stream())
+    _lib.check(rc, "cdl_project_filters")
+    return w
+
+
+def gabor_filters(alpha, a, w0, psi, P, transpose):
+    alpha, a, w0, psi = (_dev(v, n) for v, n in ((alpha, "alpha"), (a, "a"), (w0, "w0"), (psi, "psi")))
+    order, M, C = psi.shape
+    w = torch.empty((M, C, P, P), device=psi.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_gabor_filters(_ptr(alpha), _ptr(a), _ptr(w0), _ptr(psi), _ptr(w), order, M, C,
+                                      P, int(bool(transpose)), _stream())
+    _lib.check(rc, "cdl_gabor_filters")
+    return w
+
+
+def gabor_filters_bwd(alpha, a, w0, psi, dw, P, transpose):
+    alpha, a, w0, psi, dw = (_dev(v, n) for v, n in ((alpha, "alpha"), (a, "a"), (w0, "w0"),
+                                                      (psi, "psi"), (dw, "dw")))
+    order, M, C = psi.shape
+    outs = [torch.empty_like(v) for v in (alpha, a, w0, psi)]
+    rc = _lib.lib().cdl_gabor_filters_bwd(_ptr(alpha), _ptr(a), _ptr(w0), _ptr(psi), _ptr(dw),
+                                          *(_ptr(o) for o in outs), order, M, C, P,
+                                          int(bool(transpose)), _stream())
+    _lib.check(rc, "cdl_gabor_filters_bwd")
+    return outs

@@ -1,0 +1,128 @@
+/* cdlnet_hip.h -- C ABI of libcdlnet_hip.so: the MI355X (gfx950) kernels behind the
+ * unrolled-ISTA hot path of RQLuo/CDLNet-video.
+ *
+ * The reference has no FFI / plugin layer (it is 100 % Python on ATen); its boundary for
+ * this path is the nn.Module surface of `model/net.py`.  The Python host package
+ * (`cdlnet-video_amd/`) mirrors that surface and calls the entry points below through
+ * ctypes; a maintainer of the reference would bind exactly these (INTEGRATION.md shows
+ * the stub).  Each entry point names the reference lines whose ATen calls it replaces.
+ *
+ * Conventions
+ *   - plain pointers and ints only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in practice), fp32 unless a name says otherwise;
+ *   - tensors are contiguous, row-major, in the reference's own layouts:
+ *       image-like   (N, C, D, H, W)      "thin"  (C = 1 or 3)
+ *       code-like    (N, M, Dz, Hz, Wz)   "fat"   (M = 32..169), Dz = D/sd, ...
+ *       filter bank  (M, C, Pd, Ph, Pw)   -- Conv{2,3}d.weight and ConvTranspose{2,3}d.weight
+ *                                            share this shape (net.py:32-33, 137-142)
+ *     2-D nets are the D = Pd = sd = 1, pd = 0 special case;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and do not
+ *     synchronise; no global state, re-entrant across streams / ranks;
+ *   - return 0 on success, a negative value on error: -(hipError_t) for runtime errors,
+ *     CDL_EINVAL / CDL_EUNSUPPORTED for argument errors.  Nothing throws.
+ *   - in-place is allowed only where a parameter says "inout".
+ */
+#ifndef CDLNET_HIP_H
+#define CDLNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDL_EINVAL        (-10001)
+#define CDL_EUNSUPPORTED  (-10002)
+
+/* Geometry of one analysis/synthesis operator pair.  D,H,W are the extents of the
+ * (reflect-padded) image, multiples of the stride; the code extents are D/sd, H/sh, W/sw.
+ * Zero padding p = (P-1)/2 for CDLNet (net.py:32), P/2 per axis for CDLNetVideo (net.py:138). */
+typedef struct cdl_geom {
+    int N, C, M;
+    int D, H, W;
+    int Pd, Ph, Pw;
+    int pd, ph, pw;
+    int sd, sh, sw;
+} cdl_geom;
+
+const char *cdl_version(void);
+
+/* ---- boundary of the loop: model/utils.py:5-22 (pre_process), :70-87 (pre_process_3d) -------
+ * mean[n] = sum(y[n]) / (mask ? sum(mask[n]) : numel);  yp = reflect_pad(mask * (y - mean));
+ * mask_p = reflect_pad(mask).  pads = {d_lo, d_hi, h_lo, h_hi, w_lo, w_hi} (floor/ceil split,
+ * utils.py:35-51).  y: (N,C,D,H,W) unpadded; yp/mask_p: (N,C,D+..,H+..,W+..). */
+int cdl_preprocess(const float *y, const float *mask /*nullable*/, float *yp,
+                   float *mask_p /*nullable iff mask is*/, float *mean /*N*/,
+                   int N, int C, int D, int H, int W, const int pads[6], void *stream);
+
+/* model/utils.py:24-33 (post_process), :89-101: xhat = crop(xp) + mean. D,H,W = unpadded. */
+int cdl_postprocess(const float *xp, const float *mean, float *xhat,
+                    int N, int C, int D, int H, int W, const int pads[6], void *stream);
+
+/* Adjoint of the crop in cdl_postprocess (autograd of utils.py:26-27): gxp = zero outside the
+ * crop window, gxhat inside.  D,H,W = unpadded extents of gxhat; gxp has the padded extents. */
+int cdl_postprocess_bwd(const float *gxhat, float *gxp, int N, int C, int D, int H, int W,
+                        const int pads[6], void *stream);
+
+/* tau[k,n,m] = t[k,0,m] + c[n] * t[k,1,m]   (net.py:82,85,87; c = sigma/255 or absent = 0) */
+int cdl_thresholds(const float *t /*K,2,M*/, const float *c /*N, nullable*/, float *tau /*K,N,M*/,
+                   int K, int N, int M, void *stream);
+
+/* Stand-alone ST(x, t) = sign(x)*relu(|x|-t) (net.py:11-14) over a code-like tensor:
+ * out[i] = ST(x[i], tau[i / per_m]) for `rows` = N*M rows of `per_m` elements.  In the nets the
+ * shrinkage is fused into cdl_analysis; this exists for callers of the reference's helper. */
+int cdl_shrink(const float *x, const float *tau /*rows*/, float *out, int rows, size_t per_m,
+               void *stream);
+
+/* ---- analysis half: F.conv2d / F.conv3d at net.py:85,87,200,205 and gabor.py:55 ------------
+ *   acc  = alpha * corr(x ; w)                         x thin, w (M,C,P..), acc fat
+ *   base = zin ? (gate ? (gate != 0 ? zin : 0) : zin) : 0
+ *   out  = tau ? ST(base + acc, tau[n,m]) : base + acc,  ST(u,t) = sign(u)*max(|u|-t,0) (net.py:11-14)
+ * Forward k=0: (alpha=+1, zin=NULL, tau).  Forward k>=1: (alpha=-1, zin=z_k, tau) with
+ * x = mask*B_k z_k - yp.  Backward: g_k = [z_{k+1}!=0]*g_{k+1} + corr(q ; B_k) is
+ * (alpha=+1, zin=g_{k+1}, gate=z_{k+1}, tau=NULL).  out must not alias zin. */
+int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha,
+                 const float *zin /*nullable*/, const float *gate /*nullable*/,
+                 const float *tau /*N*M, nullable*/, float *out, void *stream);
+
+/* ---- synthesis half: F.conv_transpose2d/3d at net.py:87,90,205,210 and gabor.py:64 ----------
+ *   v   = alpha * corrT( gate ? [gate!=0]*z : z ; w )   z fat, v thin, output_padding = s-1
+ *   out = (mask ? mask*v : v) - (sub ? sub : 0)
+ * Forward residual r_k = mask*B_k z_k - yp: (alpha=1, mask, sub=yp).  Dictionary synthesis
+ * D z_K: (alpha=1, NULL, NULL).  Backward q_k = mask * (-A_k^T du): (z=g, gate=z_{k+1}, alpha=-1, mask). */
+int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate /*nullable*/,
+                  const float *w, float alpha, const float *mask /*nullable*/,
+                  const float *sub /*nullable*/, float *out, void *stream);
+
+/* ---- filter gradients (autograd of the two conv calls above; train.py:98) --------------------
+ *   dw[m,c,kd,ki,kj] = alpha * sum_{n,zd,zy,zx} zg[n,m,zd,zy,zx] * x[n,c,zd*sd-pd+kd, zy*sh-ph+ki, zx*sw-pw+kj]
+ * with zg = gate ? [gate!=0]*z : z.  dA_k: (z=g_{k+1}, gate=z_{k+1}, x=r_k, alpha=-1);
+ * dB_k: (z=z_k, x=q_k, alpha=+1).  Deterministic (no atomics).  Pw <= 16. dw is overwritten. */
+int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate /*nullable*/, const float *x,
+              float alpha, float *dw, void *stream);
+
+/* Threshold gradients of one iteration: with du = [zout!=0]*g,
+ *   dt0[m] = -sum_{n,pix} sign(zout)*du,   dt1[m] = -sum_n c[n] * sum_pix sign(zout)*du
+ * (c NULL -> dt1 = 0).  scratch: N*M floats. dt0/dt1 are overwritten. */
+int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c /*N, nullable*/,
+                 float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*N*M*/, void *stream);
+
+/* model/solvers.py:24-28 (uball_project) applied by net.py:72-73,189-190: every filter
+ * (consecutive `flen` floats) with l2 norm > 1 is scaled onto the unit sphere.  w inout. */
+int cdl_project_filters(float *w, int nfilters, int flen, void *stream);
+
+/* model/gabor.py:7-28,46-51 (gabor_kernel, get_filter): w[m,c,i,j] = sum_o alpha[o,m,c] *
+ * exp(-(a0*(i-x0))^2 - (a1*(j-x0))^2) * cos(sgn*(w00*(i-x0) + w01*(j-x0) + psi)),
+ * x0=(P-1)/2, sgn=-1 for the analysis ("transpose") filter.  alpha (O,M,C), a,w0 (O,M,C,2), psi (O,M,C). */
+int cdl_gabor_filters(const float *alpha, const float *a, const float *w0, const float *psi,
+                      float *w /*M,C,P,P*/, int order, int M, int C, int P, int transpose, void *stream);
+
+/* Backward of cdl_gabor_filters: given dw (M,C,P,P) writes dalpha, da, dw0, dpsi (overwritten). */
+int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, const float *psi,
+                          const float *dw, float *dalpha, float *da, float *dw0, float *dpsi,
+                          int order, int M, int C, int P, int transpose, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDLNET_HIP_H */

@@ -1,0 +1,220 @@
+"""Operator-level parity: every C-ABI entry point against the CPU oracle on seeded inputs."""
+import pytest
+import torch
+
+from gpu_util import check
+from oracle import cdl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def ops():
+    import cdlnet_video_amd as cva
+    return cva.ops
+
+
+# (N, C, M, spatial, P, stride)
+SHAPES = [
+    (2, 1, 8, (20, 24), (5, 5), 1),
+    (1, 1, 64, (40, 36), (7, 7), 1),
+    (2, 3, 9, (18, 22), (7, 7), 1),
+    (2, 1, 6, (24, 20), (7, 7), 2),
+    (1, 3, 5, (16, 12), (3, 5), 2),
+    (1, 1, 6, (8, 16, 16), (5, 5, 5), 1),
+    (2, 1, 5, (8, 12, 20), (9, 9, 5), 2),
+    (1, 2, 4, (6, 9, 12), (3, 3, 3), 3),
+    (1, 1, 169, (16, 18), (7, 7), 2),
+]
+
+
+def make(N, C, M, sp, P, s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((N, C) + sp, generator=g)
+    zsp = tuple(d // s for d in sp)
+    z = torch.randn((N, M) + zsp, generator=g)
+    z = z * (torch.rand(z.shape, generator=g) < 0.3)          # sparse code with exact zeros
+    w = torch.randn((M, C) + P, generator=g) * 0.2
+    return x, z, w
+
+
+@pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
+def test_analysis_variants(N, C, M, sp, P, s):
+    o = ops()
+    x, z, w = make(N, C, M, sp, P, s)
+    pad = tuple(p // 2 for p in P)
+    geom = o.Geometry.make(N, C, M, sp, P, pad, s)
+    ref_conv = O.analysis(x, w, s, pad)
+    tau = torch.rand(N, M) * 0.5 - 0.1                          # includes negative thresholds
+    tb = tau.reshape((N, M) + (1,) * len(sp))
+    xd, zd, wd = x.cuda(), z.cuda(), w.cuda()
+    tag = f"analysis N{N}C{C}M{M}{sp}P{P}s{s}"
+    check(tag + " plain", o.analysis(geom, xd, wd), ref_conv, 2e-6)
+    check(tag + " first", o.analysis(geom, xd, wd, 1.0, None, None, tau.cuda()),
+          O.soft_threshold(ref_conv, tb), 4e-6)
+    check(tag + " iter", o.analysis(geom, xd, wd, -1.0, zd, None, tau.cuda()),
+          O.soft_threshold(z - ref_conv, tb), 4e-6)
+    gup = torch.randn(z.shape)
+    check(tag + " bwd", o.analysis(geom, xd, wd, 1.0, gup.cuda(), zd, None),
+          gup * (z != 0) + ref_conv, 2e-6)
+
+
+@pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
+def test_synthesis_variants(N, C, M, sp, P, s):
+    o = ops()
+    x, z, w = make(N, C, M, sp, P, s, seed=1)
+    pad = tuple(p // 2 for p in P)
+    geom = o.Geometry.make(N, C, M, sp, P, pad, s)
+    ref = O.synthesis(z, w, s, pad)
+    assert ref.shape == x.shape
+    mask = (torch.rand(x.shape) < 0.4).float()
+    zd, wd = z.cuda(), w.cuda()
+    tag = f"synthesis N{N}C{C}M{M}{sp}P{P}s{s}"
+    check(tag + " plain", o.synthesis(geom, zd, wd), ref, 2e-6)
+    check(tag + " resid", o.synthesis(geom, zd, wd, 1.0, None, mask.cuda(), x.cuda()), mask * ref - x, 2e-6)
+    gup = torch.randn(z.shape)
+    ref_b = -mask * O.synthesis(gup * (z != 0), w, s, pad)
+    check(tag + " bwd", o.synthesis(geom, gup.cuda(), wd, -1.0, zd, mask.cuda(), None), ref_b, 2e-6)
+
+
+@pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
+def test_filter_and_threshold_grads(N, C, M, sp, P, s):
+    o = ops()
+    x, z, w = make(N, C, M, sp, P, s, seed=2)
+    pad = tuple(p // 2 for p in P)
+    geom = o.Geometry.make(N, C, M, sp, P, pad, s)
+    # d/dw of <analysis(x; w), u> = sum u (x) x: autograd on the oracle is the reference
+    wv = w.clone().requires_grad_(True)
+    u = torch.randn(z.shape)
+    (O.analysis(x, wv, s, pad) * (u * (z != 0))).sum().backward()
+    tag = f"wgrad N{N}C{C}M{M}{sp}P{P}s{s}"
+    check(tag + " gated", o.wgrad(geom, u.cuda(), x.cuda(), 1.0, gate=z.cuda()), wv.grad, 1e-5)
+    wv.grad = None
+    (O.synthesis(z, wv, s, pad) * x).sum().backward()
+    check(tag + " synth", o.wgrad(geom, z.cuda(), x.cuda(), -2.0), -2.0 * wv.grad, 1e-5)
+    # threshold gradient
+    c = torch.rand(N)
+    dt = torch.zeros(2, M, device="cuda")
+    o.tau_grad(geom, u.cuda(), z.cuda(), c.cuda(), dt)
+    s_nm = -(torch.sign(z) * u).sum(dim=tuple(range(2, z.dim())))
+    check(tag + " dt0", dt[0], s_nm.sum(0), 1e-5)
+    check(tag + " dt1", dt[1], (c[:, None] * s_nm).sum(0), 1e-5)
+
+
+@pytest.mark.parametrize("shape,s,masked", [((2, 1, 33, 31), 2, False), ((3, 3, 21, 19), 2, True),
+                                            ((2, 1, 32, 32), 1, False), ((1, 1, 7, 13, 11), 2, False),
+                                            ((2, 3, 17, 20), 4, True), ((1, 2, 5, 6, 7), 4, True)])
+def test_pre_and_post_process(shape, s, masked):
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    y = torch.rand(shape, generator=g)
+    mask = (torch.rand(shape, generator=g) < 0.5).float() if masked else None
+    if masked:
+        y = y * mask
+    yp, mean, pads, mask_p = O.preprocess(y, s, mask)
+    yp_d, mean_d, pads_d, mask_d = o.preprocess(y.cuda(), s, None if mask is None else mask.cuda())
+    assert tuple(pads_d) == tuple(pads)
+    tag = f"preprocess {shape} s{s} mask{masked}"
+    check(tag + " yp", yp_d, yp, 2e-6)
+    check(tag + " mean", mean_d, mean.reshape(-1), 2e-6)
+    if masked:
+        assert torch.equal(mask_d.cpu(), mask_p)
+    xp = torch.randn(yp.shape, generator=g)
+    check(tag + " post", o.postprocess(xp.cuda(), mean_d, pads), O.postprocess(xp, mean, pads), 2e-6)
+    gx = torch.randn(shape, generator=g)
+    full = torch.zeros(yp.shape)
+    idx = [slice(None), slice(None)]
+    nsp = len(shape) - 2
+    for d in range(nsp):
+        lo, hi = pads[2 * (nsp - 1 - d)], pads[2 * (nsp - 1 - d) + 1]
+        idx.append(slice(lo, yp.shape[2 + d] - hi))
+    full[tuple(idx)] = gx
+    assert torch.equal(o.postprocess_bwd(gx.cuda(), pads).cpu(), full)
+
+
+def test_thresholds_and_shrink():
+    o = ops()
+    g = torch.Generator().manual_seed(4)
+    t = torch.rand(5, 2, 7, 1, 1, generator=g) * 0.1
+    c = torch.rand(3, generator=g)
+    tau = o.thresholds(t.cuda(), c.cuda(), 3).cpu()
+    ref = t[:, 0].reshape(5, 1, 7) + c.reshape(1, 3, 1) * t[:, 1].reshape(5, 1, 7)
+    assert torch.equal(tau, ref)
+    assert torch.equal(o.thresholds(t.cuda(), None, 3).cpu(), t[:, 0].reshape(5, 1, 7).expand(5, 3, 7))
+    x = torch.randn(3, 7, 9, 11, generator=g) * 0.1
+    x[0, 0, 0, :3] = torch.tensor([0.0, -0.0, 1e-30])
+    tt = torch.rand(3, 7, generator=g) * 0.2 - 0.05
+    got = o.shrink(x.cuda(), tt.cuda()).cpu()
+    assert torch.equal(got, O.soft_threshold(x, tt.reshape(3, 7, 1, 1)))
+    import cdlnet_video_amd as cva
+    got = cva.ST(x.cuda(), tt.reshape(3, 7, 1, 1).cuda()).cpu()
+    assert torch.equal(got, O.soft_threshold(x, tt.reshape(3, 7, 1, 1)))
+
+
+def test_golden_shrink_table(golden):
+    o = ops()
+    g = golden("f6_negative_t")
+    x = g["st_in"].reshape(1, 1, -1)
+    for row, t in zip(g["st_out"], g["st_t"].tolist()):
+        got = o.shrink(x.cuda(), torch.tensor([[t]], dtype=torch.float32).cuda()).cpu().reshape(-1)
+        assert torch.equal(got, row)
+
+
+def test_project(golden):
+    o = ops()
+    g = golden("f9_helpers")
+    w = g["W"].clone().cuda()
+    o.project_filters_(w)
+    check("project 2d vs reference uball_project", w, g["W_proj"], 1e-6)
+    w3 = g["W3"].clone().cuda()
+    o.project_filters_(w3)
+    check("project 3d vs oracle (parity unpinned: reference call raises)", w3,
+          O.unit_ball(g["W3"], (2, 3, 4)), 1e-6)
+    zero = torch.zeros(2, 1, 3, 3, device="cuda")
+    o.project_filters_(zero)
+    assert torch.equal(zero.cpu(), torch.zeros(2, 1, 3, 3))
+
+
+@pytest.mark.parametrize("order,M,C,P,tr", [(1, 6, 1, 5, False), (2, 4, 1, 7, True), (3, 5, 3, 9, False)])
+def test_gabor_bank_and_adjoint(order, M, C, P, tr):
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    alpha = torch.randn(order, M, C, 1, 1, generator=g)
+    a = torch.randn(order, M, C, 2, generator=g) * 0.4
+    w0 = torch.randn(order, M, C, 2, generator=g)
+    psi = torch.randn(order, M, C, generator=g)
+    leaves = [v.clone().requires_grad_(True) for v in (alpha, a, w0, psi)]
+    ref = O.gabor_bank(*leaves, P, tr)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    got = o.gabor_filters(alpha.cuda(), a.cuda(), w0.cuda(), psi.cuda(), P, tr)
+    tag = f"gabor o{order}M{M}C{C}P{P}T{tr}"
+    check(tag + " fwd", got, ref, 1e-5)
+    grads = o.gabor_filters_bwd(alpha.cuda(), a.cuda(), w0.cuda(), psi.cuda(), up.cuda(), P, tr)
+    for name, gg, leaf in zip(("dalpha", "da", "dw0", "dpsi"), grads, leaves):
+        check(f"{tag} {name}", gg, leaf.grad, 2e-5)
+
+
+def test_golden_gabor_filters(golden):
+    o = ops()
+    g = golden("f5_gabor_shared")
+    for k in range(3):
+        for bank, tr in (("A", True), ("B", False)):
+            got = o.gabor_filters(*(g["sd"][f"{bank}.{k}.{f}"].cuda() for f in ("alpha", "a", "w0", "psi")), 7, tr)
+            check(f"golden gabor filter {bank}.{k}", got, g["filt"][f"{bank}.{k}"], 1e-5)
+
+
+def test_bad_arguments_fail_loudly():
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    with pytest.raises(RuntimeError):
+        o.preprocess(torch.rand(1, 1, 8, 8), 1)                     # CPU tensor
+    with pytest.raises(ValueError):
+        o.Geometry.make(1, 1, 4, (8, 8), (4, 4), (2, 2), 1)         # even filter
+    with pytest.raises(ValueError):
+        o.Geometry.make(1, 1, 4, (9, 8), (3, 3), (1, 1), 2)         # extent not a stride multiple
+    geom = o.Geometry.make(1, 1, 4, (8, 8), (3, 3), (1, 1), 1)
+    z = torch.zeros(geom.code_shape(), device="cuda")
+    x = torch.zeros(geom.image_shape(), device="cuda")
+    w = torch.zeros(geom.filter_shape(), device="cuda")
+    with pytest.raises(cva.HipKernelError):
+        o.analysis(geom, x, w, 1.0, z, None, None, out=z)           # out aliases zin
