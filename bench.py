@@ -24,6 +24,25 @@ import torch                                    # noqa: E402
 import torch.distributed as dist                # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
+T_START = time.perf_counter()
+
+
+def note(msg):
+    """Progress line on stderr (the JSON result is the only thing written to stdout)."""
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores(cap=16):
+    """CPU threads this process may really use: affinity and cgroup quota, capped at the box's
+    per-GPU CPU share (oversubscribing a shared host makes the CPU baseline meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
 
 
 def parse():
@@ -96,7 +115,7 @@ def cpu_baseline(sd, x, y, sigma, K, P, reps=2):
     """The CPU oracle (PyTorch restatement of the reference, kind='port') timed on this host's cores
     on a bounded sample of the same workload: fwd+bwd of `x.shape[0]` images."""
     from oracle import cdl_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     sd = dict(sd)
     sd["D.weight"] = sd["B.0.weight"]
     O.loss_and_grads(sd, x, y, K=K, P=P, s=1, sigma=sigma, adaptive=True)            # warm-up
@@ -151,9 +170,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"model + data ready (rank {rank}/{world}); warm-up x{args.warmup}")
     for _ in range(args.warmup):
         step()
     barrier()
+    note("timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -164,6 +185,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed * 1e3 / args.steps
+    note(f"{ms_per_step:.1f} ms/step")
     pix_per_step = world * B * S * S
     value = pix_per_step / (ms_per_step * 1e-3) / 1e6
 
@@ -175,8 +197,10 @@ def main():
 
     out = None
     if rank == 0:
+        note(f"fwd-only {fwd_ms:.1f} ms; probing kernels")
         rows, dom = kernel_probe(cva, net, B, S)
         d = rows[dom]
+        note("kernel probe done")
         out = {
             "metric": f"Mpix/s denoised (fwd+bwd) at K={K},M={M},P={P}",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -198,7 +222,9 @@ def main():
             nb = min(args.cpu_batch, B)
             xs = x_cpu[:nb]
             ys = xs + torch.randn(xs.shape, generator=gen) * 25 / 255
+            note(f"CPU baseline on {host_cores()} threads")
             cpu_mpix, xref, lref, threads = cpu_baseline(sd_cpu, xs, ys, 25.0, K, P)
+            note("CPU baseline done")
             with torch.no_grad():
                 net0 = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=False)
                 net0.load_state_dict(sd_cpu)

@@ -48,7 +48,12 @@ SIGNATURES = {
     "cdl_project_filters": [_P, _I, _I, _P],
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cdl_fused2d_supported": [_G],
+    "cdl_fused2d_prep": [_P, _P, _P, _I, _I, _P],
+    "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "cdl_fused2d_assemble": [_G, _P, _P, _P, _P, _P],
 }
+SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G]}
 
 _lib = None
 
@@ -65,6 +70,10 @@ def lib():
             fn = getattr(handle, name)          # AttributeError here = header / library mismatch
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        for name, argtypes in SIZE_T_FUNCS.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_size_t
         handle.cdl_version.restype = ctypes.c_char_p
         handle.cdl_version.argtypes = []
         _lib = handle

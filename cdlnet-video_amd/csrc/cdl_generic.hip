@@ -282,7 +282,11 @@ __global__ void k_thresholds(const float *__restrict__ t, const float *__restric
     if (i >= K * N * M) return;
     int m = i % M, n = (i / M) % N, k = i / (M * N);
     float v = t[(k * 2 + 0) * M + m];
-    if (c) v = __fadd_rn(v, __fmul_rn(c[n], t[(k * 2 + 1) * M + m]));   // mul then add, as torch does
+    if (c) {
+#pragma clang fp contract(off)                     // mul then add (two roundings), as torch does
+        float prod = c[n] * t[(k * 2 + 1) * M + m];
+        v = v + prod;
+    }
     tau[i] = v;
 }
 

@@ -18,6 +18,61 @@ import torch
 
 from . import ops
 
+# Kernel selection for the forward sweep: "auto" uses the fused MFMA kernels whenever the geometry
+# has one (cdl_fused2d_supported) and the shape-generic kernels otherwise; "generic" forces the latter.
+# PRECISION applies to the fused kernels only: "split3" (fp32-grade, default) or "bf16".
+BACKEND = "auto"
+PRECISION = "split3"
+
+
+def set_backend(name):
+    global BACKEND
+    if name not in ("auto", "generic"):
+        raise ValueError(name)
+    BACKEND = name
+
+
+def set_precision(name):
+    global PRECISION
+    if name not in ops.PRECISION:
+        raise ValueError(name)
+    PRECISION = name
+
+
+def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    K = len(A)
+    codes, resid = [], []
+    z = ops.analysis(g, yp, A[0], 1.0, None, None, tau[0])
+    codes.append(z)
+    for k in range(1, K):
+        r = ops.synthesis(g, z, B[k], 1.0, None, mask_p, yp)
+        z = ops.analysis(g, r, A[k], -1.0, z, None, tau[k])
+        if keep_codes:
+            codes.append(z)
+        if keep_resid:
+            resid.append(r)
+    xp = ops.synthesis(g, z, B[0], 1.0)
+    return xp, z, codes, resid
+
+
+def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    """One launch per iteration (cdl_fused2d_iter_fwd) + a thin assemble launch."""
+    K = len(A)
+    frags = [ops.fused_prep(A[k], B[(k + 1) % K]) for k in range(K)]   # last one pairs A_{K-1} with D = B_0
+    patches = ops.fused_patches(g, yp.device)
+    codes, resid = [], []
+    r, z = yp, None
+    for k in range(K):
+        z = ops.fused_iter(g, r, z, tau[k], frags[k], 1.0 if k == 0 else -1.0, patches, PRECISION)
+        if keep_codes or k == 0:
+            codes.append(z)
+        if k < K - 1:
+            r = ops.fused_assemble(g, patches, mask_p, yp)
+            if keep_resid:
+                resid.append(r)
+    xp = ops.fused_assemble(g, patches, None, None)
+    return xp, z, codes, resid
+
 
 class UnrolledISTA(torch.autograd.Function):
     """(y, mask, c, t, A_0..A_{K-1}, B_0..B_{K-1}) -> (xhat, z_K[, z_1..z_{K-1}])."""
@@ -38,17 +93,8 @@ class UnrolledISTA(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # an unused z output must not cost a fat zero tensor
         keep = any(ctx.needs_input_grad)          # all False under torch.no_grad()
         want_codes = cfg.get("all_codes", False)
-        codes, resid = [], []
-        z = ops.analysis(g, yp, A[0], 1.0, None, None, tau[0])
-        codes.append(z)
-        for k in range(1, K):
-            r = ops.synthesis(g, z, B[k], 1.0, None, mask_p, yp)
-            z = ops.analysis(g, r, A[k], -1.0, z, None, tau[k])
-            if keep or want_codes:
-                codes.append(z)
-            if keep:
-                resid.append(r)
-        xp = ops.synthesis(g, z, B[0], 1.0)
+        sweep = _forward_fused if (BACKEND == "auto" and ops.fused_supported(g)) else _forward_generic
+        xp, z, codes, resid = sweep(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
         xhat = ops.postprocess(xp, mean, pads)
 
         ctx.geom, ctx.pads, ctx.K = g, pads, K

@@ -268,3 +268,54 @@ def gabor_filters_bwd(alpha, a, w0, psi, dw, P, transpose):
                                           int(bool(transpose)), _stream())
     _lib.check(rc, "cdl_gabor_filters_bwd")
     return outs
+
+
+# ------------------------------------------------------------------------------------------ fused MFMA path
+PRECISION = {"split3": 0, "bf16": 1}
+
+
+def fused_supported(g: Geometry) -> bool:
+    gs = g.c_struct()
+    return bool(_lib.lib().cdl_fused2d_supported(ctypes.byref(gs)))
+
+
+def fused_prep(wA, wB):
+    """bf16 hi/lo MFMA fragments for one launch: analysis bank wA with the synthesis bank wB that
+    consumes its output (B_{k+1}, or D after the last iteration)."""
+    wA, wB = _dev(wA, "wA"), _dev(wB, "wB")
+    M, P = wA.shape[0], wA.shape[-1]
+    nbytes = _lib.lib().cdl_fused2d_frag_bytes(M)
+    frags = torch.empty(nbytes, device=wA.device, dtype=torch.uint8)
+    rc = _lib.lib().cdl_fused2d_prep(_ptr(wA), _ptr(wB), _ptr(frags), M, P, _stream())
+    _lib.check(rc, "cdl_fused2d_prep")
+    return frags
+
+
+def fused_patches(g: Geometry, device):
+    gs = g.c_struct()
+    n = _lib.lib().cdl_fused2d_patch_floats(ctypes.byref(gs))
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
+def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3", out=None):
+    r, zin, tau = _dev(r, "r"), _opt(zin, "zin"), _dev(tau, "tau")
+    assert tuple(r.shape) == g.image_shape()
+    if out is None:
+        out = torch.empty(g.code_shape(), device=r.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_iter_fwd(ctypes.byref(gs), _ptr(r), _ptr(zin), _ptr(tau), _ptr(frags),
+                                         float(sgn), _ptr(out), _ptr(patches), PRECISION[precision],
+                                         _stream())
+    _lib.check(rc, "cdl_fused2d_iter_fwd")
+    return out
+
+
+def fused_assemble(g: Geometry, patches, mask=None, sub=None, out=None):
+    mask, sub = _opt(mask, "mask"), _opt(sub, "sub")
+    if out is None:
+        out = torch.empty(g.image_shape(), device=patches.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_assemble(ctypes.byref(gs), _ptr(patches), _ptr(mask), _ptr(sub),
+                                         _ptr(out), _stream())
+    _lib.check(rc, "cdl_fused2d_assemble")
+    return out

@@ -122,6 +122,27 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
                           const float *dw, float *dalpha, float *da, float *dw0, float *dpsi,
                           int order, int M, int C, int P, int transpose, void *stream);
 
+/* ==== fused MFMA path (cdl_fused2d.hip): 2-D, C = 1, stride 1, odd P <= 7, M in {32, 64} =========
+ * One launch per unrolled iteration replaces the whole body of net.py:87
+ *     z = ST(z - A_k(mask*B_k(z) - yp), tau_k)
+ * with the fusion boundary moved to the one-channel residual:
+ *     cdl_fused2d_iter_fwd :  r_k, z_k  ->  z_{k+1} = ST(z_k + sgn * A_k r_k, tau_k)   (fat, written once)
+ *                                           patches = partial B_next z_{k+1}           (thin)
+ *     cdl_fused2d_assemble :  patches  ->  r_{k+1} = mask * (B_next z_{k+1}) - yp      (thin)
+ * For k = 0 pass r = yp, zin = NULL, sgn = +1 (net.py:85); for k >= 1 sgn = -1.  For the last
+ * iteration B_next is D = B_0 and assemble(mask = sub = NULL) yields D z_K (net.py:90).
+ * precision: 0 = split-bf16 (hi+lo operands, 3 MFMAs per product, fp32-grade), 1 = plain bf16. */
+int cdl_fused2d_supported(const cdl_geom *g);              /* 1 if this geometry has a fused kernel */
+size_t cdl_fused2d_frag_bytes(int M);                      /* bytes of one prepared (A_k, B_next) pair */
+size_t cdl_fused2d_patch_floats(const cdl_geom *g);        /* floats in the patch workspace */
+/* fp32 filters (M,1,P,P) -> bf16 hi/lo MFMA operand fragments for one launch (A_k with B_next). */
+int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P, void *stream);
+int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/,
+                         const float *tau /*N*M*/, const void *frags, float sgn, float *zout,
+                         float *patches, int precision, void *stream);
+int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *mask /*nullable*/,
+                         const float *sub /*nullable*/, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,154 @@
+"""The fused MFMA iteration (cdl_fused2d_*) against the shape-generic fp32 kernels and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import check, log
+from oracle import cdl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_bits_to_float(u16):
+    return torch.from_numpy((u16.astype(np.uint32) << 16).view(np.float32).copy())
+
+
+@pytest.mark.parametrize("M,P", [(64, 7), (32, 5), (64, 3)])
+def test_prepared_fragments_layout(M, P):
+    """hi + lo reconstructs every filter tap (to 2^-16) at the documented fragment position."""
+    import cdlnet_video_amd as cva
+    g = torch.Generator().manual_seed(0)
+    wA = torch.randn(M, 1, P, P, generator=g)
+    wB = torch.randn(M, 1, P, P, generator=g)
+    frags = cva.ops.fused_prep(wA.cuda(), wB.cuda()).cpu().numpy().view(np.uint16)
+    MT = M // 32
+    FA = FB = 4 * MT
+    fr = bf16_bits_to_float(frags).reshape(2 * (FA + FB), 64, 8)
+    off = (7 - P) // 2
+
+    def emb(w, ch, i, j):
+        ii, jj = i - off, j - off
+        if i > 6 or j > 6 or ii < 0 or jj < 0 or ii >= P or jj >= P:
+            return 0.0
+        return float(w[ch, 0, ii, jj])
+
+    worst = 0.0
+    for f in range(FA):
+        R, ks = divmod(f, 4)
+        for lane in (0, 5, 31, 32, 47, 63):
+            row, h = lane & 31, lane >> 5
+            for e in range(8):
+                ref = emb(wA, 32 * R + row, e, 2 * ks + h)
+                got = float(fr[f, lane, e] + fr[FA + f, lane, e])
+                worst = max(worst, abs(got - ref) / max(abs(ref), 1e-3))
+    for gidx in range(FB):
+        Rp, kb = divmod(gidx, 2 * MT)
+        R, s = kb >> 1, kb & 1
+        for lane in (0, 9, 31, 32, 50, 63):
+            row, h = lane & 31, lane >> 5
+            tap = 32 * Rp + row
+            for e in range(8):
+                ch = 32 * R + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)
+                ref = emb(wB, ch, tap >> 3, tap & 7)
+                got = float(fr[2 * FA + gidx, lane, e] + fr[2 * FA + FB + gidx, lane, e])
+                worst = max(worst, abs(got - ref) / max(abs(ref), 1e-3))
+    log(f"prep fragments M{M} P{P} worst hi+lo reconstruction error {worst:.2e}")
+    assert worst < 2.0 ** -15
+
+
+SHAPES = [  # N, M, P, H, W, masked
+    (1, 64, 7, 16, 64, False),        # exactly one tile
+    (2, 64, 7, 50, 70, True),         # ragged tiles in both directions
+    (1, 32, 5, 33, 65, False),
+    (2, 64, 3, 40, 130, False),
+    (3, 32, 7, 16, 200, True),
+    (1, 64, 7, 128, 128, False),
+]
+
+
+@pytest.mark.parametrize("N,M,P,H,W,masked", SHAPES)
+@pytest.mark.parametrize("precision,tol", [("split3", 2e-5), ("bf16", 3e-2)])
+def test_fused_iteration_vs_generic(N, M, P, H, W, masked, precision, tol):
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    gen = torch.Generator().manual_seed(H * W + M)
+    geom = o.Geometry.make(N, 1, M, (H, W), (P, P), (P // 2, P // 2), 1)
+    assert o.fused_supported(geom)
+    r = torch.randn(N, 1, H, W, generator=gen).cuda()
+    z = (torch.randn(N, M, H, W, generator=gen) * (torch.rand(N, M, H, W, generator=gen) < 0.3)).cuda()
+    wA = (torch.randn(M, 1, P, P, generator=gen) * 0.15).cuda()
+    wB = (torch.randn(M, 1, P, P, generator=gen) * 0.15).cuda()
+    tau = (torch.rand(N, M, generator=gen) * 0.6 - 0.05).cuda()
+    yp = torch.randn(N, 1, H, W, generator=gen).cuda()
+    mask = (torch.rand(N, 1, H, W, generator=gen) < 0.5).float().cuda() if masked else None
+    frags = o.fused_prep(wA, wB)
+    patches = o.fused_patches(geom, "cuda")
+    tag = f"fused[{precision}] N{N}M{M}P{P} {H}x{W}"
+    for name, zin, sgn in (("iter", z, -1.0), ("first", None, 1.0)):
+        z_ref = o.analysis(geom, r, wA, sgn, zin, None, tau)
+        r_ref = o.synthesis(geom, z_ref, wB, 1.0, None, mask, yp)
+        patches.fill_(float("nan"))                       # every patch word that is read must be written
+        z_got = o.fused_iter(geom, r, zin, tau, frags, sgn, patches, precision)
+        r_got = o.fused_assemble(geom, patches, mask, yp)
+        check(f"{tag} {name} z'", z_got, z_ref, tol)
+        # the synthesis check feeds the fused kernel's own z' to the generic kernel: isolates the second GEMM
+        check(f"{tag} {name} r_next", r_got, o.synthesis(geom, z_got, wB, 1.0, None, mask, yp), tol)
+        check(f"{tag} {name} r_next(end-to-end)", r_got, r_ref, 4 * tol)
+        if precision == "split3":
+            same_support = float(((z_got != 0) == (z_ref != 0)).float().mean())
+            assert same_support > 0.9999
+
+
+@pytest.mark.parametrize("backend", ["auto", "generic"])
+@pytest.mark.parametrize("label,K,M,P,shape", [
+    ("cfg1 K10 M32 P5 1x128x128", 10, 32, 5, (1, 1, 128, 128)),
+    ("cfg2-arch K30 M64 P7 2x100x90", 30, 64, 7, (2, 1, 100, 90)),
+])
+def test_net_forward_both_backends_vs_oracle(backend, label, K, M, P, shape):
+    """The 1e-5 gate of the north star, through the fused (auto) and the generic kernels."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    torch.manual_seed(5)
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_ not in ("t", "g"):
+                p_.add_(0.03 * p_.abs().mean() * torch.randn_like(p_))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = cva.utils.synthetic_clip(shape, seed=9)
+    y, sig = cva.awgn(x, (20, 30), torch.Generator().manual_seed(10))
+    xr, zr = O.ista(sd, y, K=K, P=P, s=1, sigma=sig, adaptive=True)
+    net = net.cuda()
+    loop.set_backend(backend)
+    try:
+        with torch.no_grad():
+            xhat, z = net(y.cuda(), sig.cuda())
+    finally:
+        loop.set_backend("auto")
+    check(f"{label} [{backend}] xhat", xhat, xr, 1e-5)
+    check(f"{label} [{backend}] z_K", z, zr, 5e-5)
+    p_ref, p_got = O.psnr(x, xr), O.psnr(x, xhat.cpu())
+    log(f"{label} [{backend}] PSNR ref={p_ref:.4f} ours={p_got:.4f}")
+    assert round(p_ref, 2) == round(p_got, 2)
+
+
+def test_bf16_precision_keeps_psnr_to_2dp():
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    torch.manual_seed(6)
+    net = cva.CDLNet(K=30, M=64, P=7, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = cva.utils.synthetic_clip((2, 1, 96, 96), seed=3)
+    y, _ = cva.awgn(x, 25, torch.Generator().manual_seed(4))
+    xr, _ = O.ista(sd, y, K=30, P=7, s=1, sigma=25.0, adaptive=True)
+    net = net.cuda()
+    loop.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            xhat, _ = net(y.cuda(), 25.0)
+    finally:
+        loop.set_precision("split3")
+    err = float((xhat.cpu() - xr).abs().max() / xr.abs().max())
+    p_ref, p_got = O.psnr(x, xr), O.psnr(x, xhat.cpu())
+    log(f"bf16 mode K30 M64 P7: xhat rel err {err:.2e} PSNR ref={p_ref:.4f} ours={p_got:.4f}")
+    assert abs(p_ref - p_got) < 0.02
