@@ -51,9 +51,13 @@ SIGNATURES = {
     "cdl_fused2d_supported": [_G],
     "cdl_fused2d_prep": [_P, _P, _P, _I, _I, _P],
     "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _I, _P],
-    "cdl_fused2d_assemble": [_G, _P, _P, _P, _P, _P],
+    "cdl_fused2d_assemble": [_G, _P, _P, _P, _F, _P, _P],
+    "cdl_fused2d_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "cdl_fused2d_dtau_reduce": [_G, _P, _P, _P, _P, _P],
+    "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
 }
-SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G]}
+SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
+                "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G]}
 
 _lib = None
 

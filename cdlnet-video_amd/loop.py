@@ -67,11 +67,57 @@ def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
         if keep_codes or k == 0:
             codes.append(z)
         if k < K - 1:
-            r = ops.fused_assemble(g, patches, mask_p, yp)
+            r = ops.fused_assemble(g, patches, mask_p, yp, 1.0)
             if keep_resid:
                 resid.append(r)
-    xp = ops.fused_assemble(g, patches, None, None)
+    xp = ops.fused_assemble(g, patches, None, None, 1.0)
     return xp, z, codes, resid
+
+
+def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+    dA, dB = [None] * K, [None] * K
+    zK = codes[K - 1]
+    if g_xp is not None:
+        dB[0] = ops.wgrad(g, zK, g_xp, 1.0)
+        gk = ops.analysis(g, g_xp, B[0], 1.0, g_z, None, None)      # B_0^T g_xp (+ g_z)
+    else:
+        dB[0] = torch.zeros_like(B[0])
+        gk = g_z.contiguous() if g_z is not None else torch.zeros_like(zK)
+    for k in range(K - 1, 0, -1):
+        z_next, z_k, r_k = codes[k], codes[k - 1], resid[k - 1]
+        ops.tau_grad(g, gk, z_next, c, dt[k])
+        q = ops.synthesis(g, gk, A[k], -1.0, z_next, mask_p, None)
+        dA[k] = ops.wgrad(g, gk, r_k, -1.0, gate=z_next)
+        dB[k] = ops.wgrad(g, z_k, q, 1.0)
+        gk = ops.analysis(g, q, B[k], 1.0, gk, z_next, None)
+    ops.tau_grad(g, gk, codes[0], c, dt[0])
+    dA[0] = ops.wgrad(g, gk, yp, 1.0, gate=codes[0])
+    return dA, dB
+
+
+def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+    """Reverse sweep on the fused kernels: per iteration one stage launch (2 fat reads, 1 fat
+    write), a thin assemble, and one MFMA filter-gradient launch (2 fat reads)."""
+    prec = PRECISION
+    dev = yp.device
+    dA, dB = [None] * K, [None] * K
+    patches = ops.fused_patches(g, dev)
+    ws = ops.fused_wgrad_workspace(g, dev)
+    dtp = torch.empty((ops.fused_tiles(g), g.M), device=dev, dtype=torch.float32)
+    thin, du_next = g_xp, g_z
+    (dB[0],) = ops.fused_wgrad(g, ws, codes[K - 1], g_xp, 1.0, precision=prec)[:1]
+    for k in range(K - 1, -1, -1):
+        frags = ops.fused_prep(B[(k + 1) % K], A[k])          # analysis-like bank, synthesis-like bank
+        du = ops.fused_stage_bwd(g, thin, du_next, codes[k], frags, patches, dtp, k >= 1, prec)
+        ops.fused_dtau_reduce(g, dtp, c, dt[k])
+        if k >= 1:
+            q = ops.fused_assemble(g, patches, mask_p, None, -1.0)
+            dA[k], dB[k] = ops.fused_wgrad(g, ws, du, resid[k - 1], -1.0, codes[k - 1], q, 1.0, prec)
+            thin = q
+        else:
+            (dA[0],) = ops.fused_wgrad(g, ws, du, yp, 1.0, precision=prec)[:1]
+        du_next = du
+    return dA, dB
 
 
 class UnrolledISTA(torch.autograd.Function):
@@ -93,7 +139,8 @@ class UnrolledISTA(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # an unused z output must not cost a fat zero tensor
         keep = any(ctx.needs_input_grad)          # all False under torch.no_grad()
         want_codes = cfg.get("all_codes", False)
-        sweep = _forward_fused if (BACKEND == "auto" and ops.fused_supported(g)) else _forward_generic
+        ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
+        sweep = _forward_fused if ctx.fused else _forward_generic
         xp, z, codes, resid = sweep(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
         xhat = ops.postprocess(xp, mean, pads)
 
@@ -121,29 +168,12 @@ class UnrolledISTA(torch.autograd.Function):
         B = saved[4 + K:4 + 2 * K]
         codes = saved[4 + 2 * K:4 + 3 * K]            # z_1..z_K
         resid = saved[4 + 3 * K:]                     # r_1..r_{K-1}
-        M = g.M
-
-        dA, dB = [None] * K, [None] * K
-        dt = torch.zeros((K, 2, M), device=yp.device, dtype=torch.float32)
-
-        zK = codes[K - 1]
-        if g_xhat is not None:
-            g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads)
-            dB[0] = ops.wgrad(g, zK, g_xp, 1.0)
-            gk = ops.analysis(g, g_xp, B[0], 1.0, g_z, None, None)      # B_0^T g_xp (+ g_z)
-        else:
-            dB[0] = torch.zeros_like(B[0])
-            gk = g_z.contiguous() if g_z is not None else torch.zeros_like(zK)
-
-        for k in range(K - 1, 0, -1):
-            z_next, z_k, r_k = codes[k], codes[k - 1], resid[k - 1]
-            ops.tau_grad(g, gk, z_next, c, dt[k])
-            q = ops.synthesis(g, gk, A[k], -1.0, z_next, mask_p, None)
-            dA[k] = ops.wgrad(g, gk, r_k, -1.0, gate=z_next)
-            dB[k] = ops.wgrad(g, z_k, q, 1.0)
-            gk = ops.analysis(g, q, B[k], 1.0, gk, z_next, None)
-        ops.tau_grad(g, gk, codes[0], c, dt[0])
-        dA[0] = ops.wgrad(g, gk, yp, 1.0, gate=codes[0])
+        dt = torch.zeros((K, 2, g.M), device=yp.device, dtype=torch.float32)
+        g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads) if g_xhat is not None else None
+        if g_z is not None:
+            g_z = g_z.contiguous()
+        sweep = _backward_fused if (ctx.fused and g_xp is not None) else _backward_generic
+        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
 
         return (None, None, None, dt.reshape(t.shape), None, *dA, *dB)
 

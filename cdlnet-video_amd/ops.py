@@ -310,12 +310,69 @@ def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3"
     return out
 
 
-def fused_assemble(g: Geometry, patches, mask=None, sub=None, out=None):
+def fused_assemble(g: Geometry, patches, mask=None, sub=None, alpha=1.0, out=None):
+    """out = mask * alpha * (overlap-sum of the patches) - sub."""
     mask, sub = _opt(mask, "mask"), _opt(sub, "sub")
     if out is None:
         out = torch.empty(g.image_shape(), device=patches.device, dtype=torch.float32)
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_assemble(ctypes.byref(gs), _ptr(patches), _ptr(mask), _ptr(sub),
-                                         _ptr(out), _stream())
+                                         float(alpha), _ptr(out), _stream())
     _lib.check(rc, "cdl_fused2d_assemble")
     return out
+
+
+def fused_tiles(g: Geometry) -> int:
+    gs = g.c_struct()
+    return int(_lib.lib().cdl_fused2d_tiles(ctypes.byref(gs)))
+
+
+def fused_stage_bwd(g: Geometry, thin, base, gate, frags, patches, dtau_partial, do_synth,
+                    precision="split3", out=None):
+    """One reverse-sweep stage: du = [gate != 0] * (base + corr(thin; W1)); patches = W2^T du."""
+    thin, base, gate = _dev(thin, "thin"), _opt(base, "base"), _dev(gate, "gate")
+    if out is None:
+        out = torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_stage_bwd(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate),
+                                          _ptr(frags), _ptr(out), _ptr(patches), _ptr(dtau_partial),
+                                          int(bool(do_synth)), PRECISION[precision], _stream())
+    _lib.check(rc, "cdl_fused2d_stage_bwd")
+    return out
+
+
+def fused_dtau_reduce(g: Geometry, dtau_partial, c, dt_k):
+    assert dt_k.is_contiguous() and dt_k.numel() == 2 * g.M
+    gs = g.c_struct()
+    base = dt_k.data_ptr()
+    rc = _lib.lib().cdl_fused2d_dtau_reduce(ctypes.byref(gs), _ptr(dtau_partial), _ptr(_opt(c, "c")),
+                                            ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * g.M),
+                                            _stream())
+    _lib.check(rc, "cdl_fused2d_dtau_reduce")
+
+
+def fused_wgrad_workspace(g: Geometry, device):
+    gs = g.c_struct()
+    n = _lib.lib().cdl_fused2d_wgrad_workspace_floats(ctypes.byref(gs))
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
+def fused_wgrad(g: Geometry, workspace, X0=None, T0=None, alpha0=1.0, X1=None, T1=None, alpha1=1.0,
+                precision="split3"):
+    """Up to two filter gradients in one launch: dw_a = alpha_a * sum X_a (x) im2col(T_a)."""
+    outs = []
+    args = []
+    for X, T, al in ((X0, T0, alpha0), (X1, T1, alpha1)):
+        if X is None:
+            outs.append(None)
+            args += [None, None, 0.0, None]
+        else:
+            X, T = _dev(X, "X"), _dev(T, "T")
+            dw = torch.empty(g.filter_shape(), device=X.device, dtype=torch.float32)
+            outs.append(dw)
+            args += [_ptr(X), _ptr(T), float(al), _ptr(dw)]
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_wgrad(ctypes.byref(gs), *args, _ptr(workspace), PRECISION[precision],
+                                      _stream())
+    _lib.check(rc, "cdl_fused2d_wgrad")
+    return outs

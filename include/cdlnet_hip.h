@@ -140,8 +140,34 @@ int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P
 int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/,
                          const float *tau /*N*M*/, const void *frags, float sgn, float *zout,
                          float *patches, int precision, void *stream);
+/* out = (mask ? mask : 1) * alpha * (sum of the overlapping patches) - (sub ? sub : 0) */
 int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *mask /*nullable*/,
-                         const float *sub /*nullable*/, float *out, void *stream);
+                         const float *sub /*nullable*/, float alpha, float *out, void *stream);
+
+/* ---- fused reverse sweep (what loss.backward() does through ATen in the reference, train.py:98) ----
+ * One stage per iteration k = K-1 .. 0, same kernel skeleton as the forward launch:
+ *     g_{k+1} = base + corr(thin ; W1)          base = du_{k+1} (or dL/dz_K, nullable), thin = q_{k+1} (or
+ *                                               dL/d(D z_K)), W1 = B_{k+1} (or B_0)
+ *     du_k    = [gate != 0] * g_{k+1}           gate = z_{k+1}          -> du_out (fat, written once)
+ *     dtau    : per-workgroup partials of -sum sign(z_{k+1}) * du_k     -> dtau_partial (tiles x M)
+ *     patches : partial W2^T du_k (W2 = A_k)    -> cdl_fused2d_assemble(alpha = -1, mask) gives q_k
+ * frags = cdl_fused2d_prep(W1, W2).  do_synth = 0 for k = 0 (no q_0 is needed). */
+size_t cdl_fused2d_tiles(const cdl_geom *g);               /* workgroups (= dtau_partial rows) per launch */
+int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base /*nullable*/,
+                          const float *gate, const void *frags, float *du_out, float *patches,
+                          float *dtau_partial, int do_synth, int precision, void *stream);
+/* dt0[m] = sum over workgroups; dt1[m] = sum_n c[n] * (sum over the workgroups of image n); c nullable */
+int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c /*N*/,
+                            float *dt0 /*M*/, float *dt1 /*M*/, void *stream);
+
+/* Filter gradients on the matrix cores: up to two independent reductions per launch
+ *     dw_a[m,i,j] = alpha_a * sum_{n,y,x} Xa[n,m,y,x] * Ta[n,y-p+i,x-p+j]     (a = 0, 1; either may be absent)
+ * e.g. (Xa,Ta,alpha) = (du_k, r_k, -1) -> dA_k and (z_k, q_k, +1) -> dB_k.  Two-stage and deterministic:
+ * per-workgroup partial sums in `workspace`, then a fixed-order reduction.  workspace_floats() floats. */
+size_t cdl_fused2d_wgrad_workspace_floats(const cdl_geom *g);
+int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float alpha0, float *dw0,
+                      const float *X1, const float *T1, float alpha1, float *dw1,
+                      float *workspace, int precision, void *stream);
 
 #ifdef __cplusplus
 }
