@@ -43,7 +43,7 @@ constexpr int RTC = RTW + 2;                // columns kept in LDS (col 70 is th
 constexpr int PITCH = 28;                   // bf16 elements per LDS column (56 B: conflict-free b64 reads)
 constexpr int COPY = RTC * PITCH;           // elements per shifted copy
 constexpr int LDS_RT = 2 * 4 * COPY * 2;    // bytes: {hi,lo} x 4 row-shifted copies
-constexpr int LDS_RSUM = RTH * RTW * 4;
+constexpr int LDS_RSUM = 4 * RTH * RTW * 4;  // one col2im slab per wave: summed in a fixed order (deterministic)
 constexpr int LDS_TAU = 64 * 4;
 
 struct FusedParams {
@@ -124,11 +124,11 @@ __global__ void k_prep(const float *__restrict__ wA, const float *__restrict__ w
 template <int MT, int PREC, int MODE>
 __global__ __launch_bounds__(256) void k_stage(FusedParams p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_RT + LDS_RSUM + 2 * LDS_TAU];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_RT + LDS_RSUM + 5 * LDS_TAU];
     __bf16 *rt = reinterpret_cast<__bf16 *>(smem);                    // [hl][q][col][PITCH]
-    float *rsum = reinterpret_cast<float *>(smem + LDS_RT);            // [RTH][RTW]
+    float *rsum_all = reinterpret_cast<float *>(smem + LDS_RT);        // [wave][RTH][RTW]
     float *tau_s = reinterpret_cast<float *>(smem + LDS_RT + LDS_RSUM);
-    float *tacc_s = tau_s + 64;                                        // backward: dtau accumulators
+    float *tacc_s = tau_s + 64;                                        // backward: [wave][64] dtau sums
 
     const int M = 32 * MT;
     int bid = blockIdx.x;
@@ -145,10 +145,8 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < (LDS_RT + LDS_RSUM) / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
-        if (tid < M) {
-            if (MODE == MODE_BWD) tacc_s[tid] = 0.0f;
-            else tau_s[tid] = p.tau[(size_t)n * M + tid];
-        }
+        if (MODE == MODE_BWD) tacc_s[tid] = 0.0f;                      // 4 x 64 floats
+        else if (tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
     }
     __syncthreads();
     {
@@ -191,6 +189,7 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
 
     const int xl = wxi * 32 + c;             // tile-local pixel column of this lane
     const int x = tx0 + xl;
+    float *rsum = rsum_all + wid * (RTH * RTW);       // this wave's slab: in-order adds of one wave only
     float ring[7][4];                        // row-direction col2im sums for halo rows yl .. yl+6, by (j & 3)
 #pragma unroll
     for (int i = 0; i < 7; ++i)
@@ -335,9 +334,13 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
                 const int i = 4 * Rp + (v >> 2);
                 if (i <= 6) ring[i][v & 3] += D[Rp][v];
             }
+        // (the two lane halves overlap in their target columns: one half per instruction keeps every
+        //  add of an instruction on a distinct word, so the summation order is fixed)
 #pragma unroll
-        for (int jl = 0; jl < 4; ++jl)
-            if (4 * h + jl <= 6) atomicAdd(&rsum[yl * RTW + xl + 4 * h + jl], ring[0][jl]);
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int jl = 0; jl < 4; ++jl)
+                if (h == hh && 4 * hh + jl <= 6) atomicAdd(&rsum[yl * RTW + xl + 4 * hh + jl], ring[0][jl]);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -355,10 +358,12 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
                 float sv = tsum[R][v];
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
-                if (c == 0) atomicAdd(&tacc_s[32 * R + 8 * (v >> 2) + 4 * h + (v & 3)], sv);
+                if (c == 0) tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = sv;
             }
         __syncthreads();
-        if (tid < M) p.dtau[(size_t)blockIdx.x * M + tid] = tacc_s[tid];
+        if (tid < M)
+            p.dtau[(size_t)blockIdx.x * M + tid] =
+                (tacc_s[tid] + tacc_s[64 + tid]) + (tacc_s[128 + tid] + tacc_s[192 + tid]);
         if (!p.do_synth) return;
     }
 
@@ -366,11 +371,15 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int jl = 0; jl < 4; ++jl)
-            if (4 * h + jl <= 6) atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * h + jl], ring[i][jl]);
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int jl = 0; jl < 4; ++jl)
+                if (h == hh && 4 * hh + jl <= 6)
+                    atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * hh + jl], ring[i][jl]);
     __syncthreads();
     float *patch = p.patches + ((size_t)(n * p.tilesY + tyi) * p.tilesX + txi) * (RTH * RTW);
-    for (int i = tid; i < RTH * RTW; i += 256) patch[i] = rsum[i];
+    for (int i = tid; i < RTH * RTW; i += 256)
+        patch[i] = (rsum_all[i] + rsum_all[RTH * RTW + i]) + (rsum_all[2 * RTH * RTW + i] + rsum_all[3 * RTH * RTW + i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -577,21 +586,25 @@ __global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
     }
 
     // ---- sum the four waves through LDS and write this workgroup's partial
-    __syncthreads();
+    // (wave 0 stores, waves 1..3 add in turn: fixed order, every lane owns its own words)
     float *red = reinterpret_cast<float *>(dsm);                               // [2][M][64]
-    for (int i = tid; i < 2 * M * 64; i += 256) red[i] = 0.0f;
-    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wid == w) {
 #pragma unroll
-    for (int op = 0; op < 2; ++op)
+            for (int op = 0; op < 2; ++op)
 #pragma unroll
-        for (int R = 0; R < MT; ++R)
+                for (int R = 0; R < MT; ++R)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+                    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int ch = 32 * R + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    atomicAdd(&red[(op * M + ch) * 64 + 32 * tt + c], acc[op][R][tt][v]);
-                }
+                        for (int v = 0; v < 16; ++v) {
+                            const int ch = 32 * R + (v & 3) + 8 * (v >> 2) + 4 * h;
+                            float *dstw = &red[(op * M + ch) * 64 + 32 * tt + c];
+                            *dstw = (w == 0 ? 0.0f : *dstw) + acc[op][R][tt][v];
+                        }
+        }
+    }
     __syncthreads();
     float *dst = p.partial + (size_t)blockIdx.x * 2 * M * 64;
     for (int i = tid; i < 2 * M * 64; i += 256) dst[i] = red[i];
