@@ -48,8 +48,8 @@ def host_cores(cap=16):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--K", type=int, default=30)
@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--P", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--precision", default="split3", choices=["split3", "bf16"],
+                    help="fused-kernel arithmetic: split-bf16 x3 (fp32-grade, default) or plain bf16")
+    ap.add_argument("--backend", default="auto", choices=["auto", "generic"])
     return ap.parse_args()
 
 
@@ -75,8 +78,11 @@ def event_ms(fn, reps):
 
 
 def kernel_probe(cva, net, batch, size, reps=5):
-    """Time each kernel family of the step on the step's own shapes; returns the table and the
-    dominant one (largest launches-per-step x average duration) with its algorithmic bytes."""
+    """Time each kernel family of the step on the step's own shapes (HIP events on the launch
+    stream); returns the table and the dominant one (launches-per-step x average duration) with its
+    algorithmic bytes: every fat (M-channel) tensor the kernel must read or write once, plus the thin
+    (one-channel) ones -- DESIGN.md section 5 lists them per kernel."""
+    from cdlnet_video_amd import loop
     o = cva.ops
     K, M, P = net.K, net.M, net.P
     N, C = batch, 1
@@ -92,16 +98,32 @@ def kernel_probe(cva, net, batch, size, reps=5):
     dt = torch.zeros(2, M, device=dev)
     fat = z.numel() * 4
     th = x.numel() * 4
-    table = {
-        # name: (callable, launches per step, algorithmic bytes per launch)
-        "k_analysis(fwd iter: z'=ST(z-A r))": (lambda: o.analysis(g, x, w, -1.0, z, None, tau, out=out), K, 2 * fat + th),
-        "k_synthesis(fwd: r=Bz-yp)": (lambda: o.synthesis(g, z, w, 1.0, None, None, x, out=thin), K, fat + 2 * th),
-        "k_analysis(bwd: g=du+B^T q)": (lambda: o.analysis(g, x, w, 1.0, gup, z, None, out=out), K, 3 * fat + th),
-        "k_synthesis(bwd: q=-A^T du)": (lambda: o.synthesis(g, gup, w, -1.0, z, None, None, out=thin), K - 1, 2 * fat + th),
-        "k_wgrad(dA)": (lambda: o.wgrad(g, gup, x, -1.0, gate=z), K, 2 * fat + th),
-        "k_wgrad(dB)": (lambda: o.wgrad(g, z, x, 1.0), K, fat + th),
-        "k_tau_partial": (lambda: o.tau_grad(g, gup, z, None, dt), K, 2 * fat),
-    }
+    if loop.BACKEND == "auto" and o.fused_supported(g):
+        prec = loop.PRECISION
+        frags = o.fused_prep(w, w)
+        patches = o.fused_patches(g, dev)
+        ws = o.fused_wgrad_workspace(g, dev)
+        dtp = torch.empty((o.fused_tiles(g), M), device=dev)
+        table = {
+            f"k_stage<FWD,{prec}> (z'=ST(z-A r), patches of B z')":
+                (lambda: o.fused_iter(g, x, z, tau, frags, -1.0, patches, prec, out=out), K, 2 * fat + 2 * th),
+            f"k_stage<BWD,{prec}> (du=[z'!=0](du'+B^T q), dtau, patches of A^T du)":
+                (lambda: o.fused_stage_bwd(g, x, gup, z, frags, patches, dtp, True, prec, out=out), K, 3 * fat + 2 * th),
+            f"k_wgrad2d<{prec}> (dA_k and dB_k)":
+                (lambda: o.fused_wgrad(g, ws, gup, x, -1.0, z, x, 1.0, prec), K, 2 * fat + 2 * th),
+            "k_assemble (thin)": (lambda: o.fused_assemble(g, patches, None, x, 1.0, out=thin), 2 * K, 3 * th),
+            "k_prep (weights -> bf16 fragments)": (lambda: o.fused_prep(w, w), 2 * K, 0),
+        }
+    else:
+        table = {
+            "k_analysis(fwd iter: z'=ST(z-A r))": (lambda: o.analysis(g, x, w, -1.0, z, None, tau, out=out), K, 2 * fat + th),
+            "k_synthesis(fwd: r=Bz-yp)": (lambda: o.synthesis(g, z, w, 1.0, None, None, x, out=thin), K, fat + 2 * th),
+            "k_analysis(bwd: g=du+B^T q)": (lambda: o.analysis(g, x, w, 1.0, gup, z, None, out=out), K, 3 * fat + th),
+            "k_synthesis(bwd: q=-A^T du)": (lambda: o.synthesis(g, gup, w, -1.0, z, None, None, out=thin), K - 1, 2 * fat + th),
+            "k_wgrad(dA)": (lambda: o.wgrad(g, gup, x, -1.0, gate=z), K, 2 * fat + th),
+            "k_wgrad(dB)": (lambda: o.wgrad(g, z, x, 1.0), K, fat + th),
+            "k_tau_partial": (lambda: o.tau_grad(g, gup, z, None, dt), K, 2 * fat),
+        }
     rows = {}
     for name, (fn, count, nbytes) in table.items():
         ms = event_ms(fn, reps)
@@ -143,6 +165,9 @@ def main():
     import cdlnet_video_amd as cva
     from cdlnet_video_amd.parallel import GradientBucket, broadcast_parameters
 
+    from cdlnet_video_amd import loop
+    loop.set_backend(args.backend)
+    loop.set_precision(args.precision)
     K, M, P, B, S = args.K, args.M, args.P, args.batch, args.size
     torch.manual_seed(1)
     net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
@@ -205,7 +230,9 @@ def main():
             "metric": f"Mpix/s denoised (fwd+bwd) at K={K},M={M},P={P}",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (split-bf16 x3 MFMA, fp32 accumulate, fp32 storage)" if args.precision == "split3"
+            else "bf16 MFMA, fp32 accumulate, fp32 storage", "data": "synthetic",
             "config": {"workload": f"CDLNet K={K} M={M} P={P} s=1 C=1 train step (fwd+bwd+Adam+project), "
                                    f"batch {B}x1x{S}x{S} per GPU, sigma=25",
                        "global_batch": world * B, "parallelism": f"dp{world}"},

@@ -191,9 +191,59 @@ def test_net_gradients_m64_vs_oracle(backend):
     finally:
         loop.set_backend("auto")
     assert abs(loss.item() - lref) < 1e-6 * lref
+    # NET_GTOL, not 2e-4: a 1e-7 difference in the forward flips the ST support of a few code
+    # elements out of ~10^6 (|u| - tau within rounding), which moves a gradient entry by ~1e-3 of
+    # the maximum -- the fp32 CPU oracle differs from an fp64 run of itself by as much
+    # (__graft_entry__.smoke note).  The arithmetic itself is pinned at 2e-5 by the kernel-level
+    # tests above and by test_fused_reverse_sweep_equals_generic_on_same_activations.
     for pname, p_ in net.named_parameters():
         if pname != "g":
-            check(f"K6 M64 P7 [{backend}] grad {pname}", p_.grad, grads[pname], 2e-4)
+            check(f"K6 M64 P7 [{backend}] grad {pname}", p_.grad, grads[pname], NET_GTOL)
+
+
+NET_GTOL = 3e-3
+
+
+@pytest.mark.parametrize("K,M,P,shape,masked", [(5, 64, 7, (2, 1, 48, 80), False), (4, 32, 5, (3, 1, 33, 70), True),
+                                                (1, 64, 7, (1, 1, 32, 64), False)])
+def test_fused_reverse_sweep_equals_generic_on_same_activations(K, M, P, shape, masked):
+    """Both reverse sweeps fed the SAME saved activations (so no support flip can enter): every
+    parameter gradient must agree to split-bf16 accuracy."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    o = cva.ops
+    torch.manual_seed(21)
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_ == "t":
+                p_.uniform_(2e-3, 2e-2)
+            elif n_ != "g":
+                p_.add_(0.05 * p_.abs().mean() * torch.randn_like(p_))
+    net = net.cuda()
+    x = cva.utils.synthetic_clip(shape, seed=5)
+    y, sig = cva.awgn(x, (20, 30), torch.Generator().manual_seed(6))
+    mask = (torch.rand(shape, generator=torch.Generator().manual_seed(7)) < 0.6).float().cuda() if masked else None
+    yp, mean, pads, mask_p = o.preprocess(y.cuda(), 1, mask)
+    N = shape[0]
+    g = o.Geometry.make(N, 1, M, yp.shape[2:], (P, P), (P // 2, P // 2), 1)
+    c = (sig.reshape(-1) / 255.0).cuda()
+    tau = o.thresholds(net.t.detach(), c, N)
+    A = [m.weight.detach() for m in net.A]
+    B = [m.weight.detach() for m in net.B]
+    xp, z, codes, resid = loop._forward_fused(g, yp, mask_p, tau, A, B, True, True)
+    g_xp = torch.randn(xp.shape, generator=torch.Generator().manual_seed(8)).cuda()
+    g_z = torch.randn(z.shape, generator=torch.Generator().manual_seed(9)).cuda() * 0.01
+    outs = {}
+    for name, sweep in (("fused", loop._backward_fused), ("generic", loop._backward_generic)):
+        dt = torch.zeros(K, 2, M, device="cuda")
+        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
+        outs[name] = (dA, dB, dt)
+    tag = f"reverse sweep K{K} M{M} P{P} {shape}"
+    for k in range(K):
+        check(f"{tag} dA[{k}]", outs["fused"][0][k], outs["generic"][0][k], 5e-5)
+        check(f"{tag} dB[{k}]", outs["fused"][1][k], outs["generic"][1][k], 5e-5)
+    check(f"{tag} dt", outs["fused"][2], outs["generic"][2], 5e-5)
 
 
 @pytest.mark.parametrize("backend", ["auto", "generic"])

@@ -175,9 +175,10 @@ def test_grads_vs_oracle_mid_size():
     sd["D.weight"] = sd["B.0.weight"]
     lref, grads, _ = O.loss_and_grads(sd, x, y, K=8, P=7, s=1, sigma=sig, adaptive=True)
     assert abs(loss.item() - lref) < 1e-6 * lref + 1e-9
+    # 3e-3: ST support flips between two fp32 evaluations of the same net (see test_gpu_fused.py NET_GTOL)
     for pname, p in net.named_parameters():
         if pname != "g":
-            check(f"mid-size grad {pname}", p.grad, grads[pname], GTOL)
+            check(f"mid-size grad {pname}", p.grad, grads[pname], 3e-3)
 
 
 # ---- size-independent properties at a BASELINE-sized input -------------------------------------
