@@ -610,38 +610,63 @@ __global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
     for (int i = tid; i < 2 * M * 64; i += 256) dst[i] = red[i];
 }
 
-// dw[ch][i'][j'] = alpha * sum_g partial[g][op][ch][8(i'+off) + (j'+off)], fixed order
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int G, float *__restrict__ dw0, float alpha0,
-                               float *__restrict__ dw1, float alpha1, int M, int P)
+// dw[ch][i'][j'] = alpha * sum_g partial[g][op][ch][8(i'+off) + (j'+off)].  32 outputs per workgroup,
+// 8 strided partial sums each, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int G,
+                                                      float *__restrict__ dw0, float alpha0,
+                                                      float *__restrict__ dw1, float alpha1, int M, int P)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + o;
     const int per = M * P * P;
-    if (t >= 2 * per) return;
-    const int op = t / per, r = t % per;
-    float *dw = op ? dw1 : dw0;
-    if (!dw) return;
-    const int ch = r / (P * P), ij = r % (P * P), off = (7 - P) / 2;
-    const int tap = 8 * (ij / P + off) + (ij % P + off);
+    const bool live = t < 2 * per;
     float sum = 0.0f;
-    for (int g = 0; g < G; ++g) sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
-    dw[r] = (op ? alpha1 : alpha0) * sum;
+    int op = 0, r = 0;
+    if (live) {
+        op = t / per; r = t % per;
+        const int ch = r / (P * P), ij = r % (P * P), off = (7 - P) / 2;
+        const int tap = 8 * (ij / P + off) + (ij % P + off);
+        for (int g = part; g < G; g += 8) sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
+    }
+    red[part][o] = sum;
+    __syncthreads();
+    if (part == 0 && live) {
+        float *dw = op ? dw1 : dw0;
+        if (dw) {
+            const float tot = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) +
+                              ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+            dw[r] = (op ? alpha1 : alpha0) * tot;
+        }
+    }
 }
 
-// dt0[m] = sum_n sum_wg partial[n][wg][m]; dt1[m] = sum_n c[n] * sum_wg partial[n][wg][m]  (fixed order)
-__global__ void k_dtau_reduce(const float *__restrict__ partial, const float *__restrict__ c,
-                              float *__restrict__ dt0, float *__restrict__ dt1, int N, int per_img, int M)
+// dt0[m] = sum_rows partial[row][m]; dt1[m] = sum_rows c[row / per_img] * partial[row][m]; one
+// workgroup, 16 strided partial sums per channel, fixed combination order (deterministic).
+__global__ __launch_bounds__(1024) void k_dtau_reduce(const float *__restrict__ partial,
+                                                      const float *__restrict__ c, float *__restrict__ dt0,
+                                                      float *__restrict__ dt1, int N, int per_img, int M)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    __shared__ float r0[16][64], r1[16][64];
+    const int m = threadIdx.x & 63, part = threadIdx.x >> 6;
     float a0 = 0.0f, a1 = 0.0f;
-    for (int n = 0; n < N; ++n) {
-        float sn = 0.0f;
-        for (int w = 0; w < per_img; ++w) sn += partial[((size_t)n * per_img + w) * M + m];
-        a0 += sn;
-        if (c) a1 = fmaf(c[n], sn, a1);
+    const int rows = N * per_img;
+    if (m < M)
+        for (int row = part; row < rows; row += 16) {
+            const float v = partial[(size_t)row * M + m];
+            a0 += v;
+            if (c) a1 = fmaf(c[row / per_img], v, a1);
+        }
+    r0[part][m] = a0;
+    r1[part][m] = a1;
+    __syncthreads();
+    if (part == 0 && m < M) {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { s0 += r0[q][m]; s1 += r1[q][m]; }
+        dt0[m] = s0;
+        dt1[m] = s1;
     }
-    dt0[m] = a0;
-    dt1[m] = a1;
 }
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -741,7 +766,7 @@ int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const 
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
     const int per_img = ((g->W + TW - 1) / TW) * ((g->H + TH - 1) / TH);
-    k_dtau_reduce<<<(g->M + 63) / 64, 64, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, per_img, g->M);
+    k_dtau_reduce<<<1, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, per_img, g->M);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -790,7 +815,7 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     }
     CDL_LAUNCH_CHECK();
     const int total = 2 * g->M * g->Ph * g->Pw;
-    k_wgrad_reduce<<<(total + 255) / 256, 256, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
+    k_wgrad_reduce<<<(total + 31) / 32, 256, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
                                                                X1 ? dw1 : nullptr, alpha1, g->M, g->Ph);
     CDL_LAUNCH_CHECK();
     return 0;
