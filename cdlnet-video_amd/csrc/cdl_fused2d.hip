@@ -15,17 +15,19 @@
 //   synthesis  col[tap][px] = sum_ch W_B^T[tap][ch] * z'[ch][px]           MFMA, z' fed straight from the
 //                                                                          accumulator registers (no LDS)
 //   col2im     rsum[y-3+i][x-3+j] += col[(i,j)][y,x]                       row direction summed in registers
-//                                                                          across the wave's 8 rows, column
-//                                                                          direction through ds_add_f32
+//                                                                          (7-row ring), column direction
+//                                                                          through ds_add_f32
 //
 // fp32-grade accuracy on bf16 matrix cores: every operand is split v = hi + lo (two bf16) and each
 // product is hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error ~2^-16 per product, random
 // sign; measured end-to-end parity is recorded in DESIGN.md).  PREC = 1 drops the lo terms (plain bf16).
 //
-// Work decomposition: workgroup = 256 threads = 4 waves = 64 x 16 pixel tile of one image
-// (2 x 2 waves of 32 x 8); grid = N * tilesY * tilesX.  Each workgroup writes its (16+6) x (64+6)
-// partial synthesis patch; k_assemble sums the <= 4 overlapping patches per pixel in a fixed order
-// (deterministic, no atomics in HBM) and applies mask / -yp.
+// Work decomposition: workgroup = 512 threads = 8 waves (2 per SIMD, so one wave's memory waits are
+// covered by its partner's MFMAs) = 64 x 32 pixel tile of one image (2 x 4 waves of 32 x 8);
+// grid = N * tilesY * tilesX.  Weight fragments live in LDS (32 KB, shared by the 8 waves).  Each
+// workgroup writes its (32+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
+// patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
+// filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
 #include "cdl_common.h"
 
 namespace {
@@ -34,17 +36,24 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int WX = 2, WY = 2;               // waves per workgroup along x / y
+constexpr int WX = 2, WY = 4;               // waves per workgroup along x / y
+constexpr int NW = WX * WY;                 // 8 waves
+constexpr int NT = 64 * NW;                 // 512 threads
 constexpr int RB = 8;                       // row blocks (image rows) per wave
-constexpr int TW = 32 * WX, TH = RB * WY;   // 64 x 16 tile
+constexpr int TW = 32 * WX, TH = RB * WY;   // 64 x 32 tile
 constexpr int HALO = 3;                     // filters are embedded in a 7 x 7 (padded 8 x 8) tap grid
-constexpr int RTW = TW + 2 * HALO, RTH = TH + 2 * HALO;   // 70 x 22 residual tile / patch
+constexpr int RTW = TW + 2 * HALO, RTH = TH + 2 * HALO;   // 70 x 38 residual tile / patch
 constexpr int RTC = RTW + 2;                // columns kept in LDS (col 70 is the zero-weight pad tap)
-constexpr int PITCH = 28;                   // bf16 elements per LDS column (56 B: conflict-free b64 reads)
+constexpr int PITCH = 44;                   // bf16 elements per LDS column (88 B: conflict-free b64 reads)
 constexpr int COPY = RTC * PITCH;           // elements per shifted copy
-constexpr int LDS_RT = 2 * 4 * COPY * 2;    // bytes: {hi,lo} x 4 row-shifted copies
-constexpr int LDS_RSUM = 4 * RTH * RTW * 4;  // one col2im slab per wave: summed in a fixed order (deterministic)
+constexpr int LDS_RT = 2 * 4 * COPY * 2;    // bytes: {hi,lo} x 4 row-shifted copies             (50688)
+constexpr int SLAB = RTH * RTW;             // floats per col2im slab
+constexpr int LDS_RSUM = 4 * SLAB * 4;      // 4 slabs by wave parity (wxi&1, wyi&1): waves sharing a slab
+                                            // never touch the same word, slabs are summed in a fixed order
+constexpr int LDS_W = 32 * 64 * 16;         // 32 weight fragments of 1 KB (split3, M = 64)
 constexpr int LDS_TAU = 64 * 4;
+constexpr int LDS_TACC = NW * 64 * 4;
+constexpr int LDS_STAGE = LDS_RT + LDS_RSUM + LDS_W + LDS_TAU + LDS_TACC;
 
 struct FusedParams {
     const float *r;          // (N,H,W) thin input of the analysis-like half (r_k, yp, q_{k+1} or g_xp)
@@ -118,19 +127,60 @@ __global__ void k_prep(const float *__restrict__ wA, const float *__restrict__ w
     lo_dst[lane] = __builtin_bit_cast(uint4, lo);
 }
 
+// Fat tensors are addressed through buffer descriptors: the descriptor covers one image's (M,H,W)
+// block, the per-lane part of the address is ONE 32-bit VGPR byte offset shared by every channel of
+// the block and the channel stride goes in an SGPR -- no 64-bit per-access address registers, and an
+// out-of-image lane simply carries an out-of-range offset (loads return 0, stores are dropped).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fat_rsrc(const float *base, size_t img_floats)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(img_floats * 4), 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+constexpr int OOB = 0x7fff0000;              // byte offset beyond any descriptor range
+
+// Sum over the 32 pixel lanes of each half-wave of N per-lane values, leaving total #i on lane
+// (c with c mod N == i): a halving butterfly, N-1 exchanges instead of 5N.
+template <int N>
+__device__ __forceinline__ float lane_transpose_sum(float (&v)[N], int c)
+{
+#pragma unroll
+    for (int n = N / 2, bit = (N == 32 ? 16 : 8); n >= 1; n >>= 1, bit >>= 1) {
+        const bool up = (c & bit) != 0;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const float keep = up ? v[k + n] : v[k];
+            const float send = up ? v[k] : v[k + n];
+            v[k] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    float r = v[0];
+    if (N == 16) r += __shfl_xor(r, 16, 64);           // lanes c and c^16 hold halves of the same index
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // MODE_FWD / MODE_FIRST: zout = ST(zin + sgn * A r, tau)              (net.py:85,87)
 // MODE_BWD            : zout = [gate != 0] * (zin + A-like r),  dtau partials   (reverse sweep)
 template <int MT, int PREC, int MODE>
-__global__ __launch_bounds__(256) void k_stage(FusedParams p)
+__global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_RT + LDS_RSUM + 5 * LDS_TAU];
-    __bf16 *rt = reinterpret_cast<__bf16 *>(smem);                    // [hl][q][col][PITCH]
-    float *rsum_all = reinterpret_cast<float *>(smem + LDS_RT);        // [wave][RTH][RTW]
-    float *tau_s = reinterpret_cast<float *>(smem + LDS_RT + LDS_RSUM);
-    float *tacc_s = tau_s + 64;                                        // backward: [wave][64] dtau sums
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *rt = reinterpret_cast<__bf16 *>(smem);                               // [hl][q][col][PITCH]
+    float *rsum_all = reinterpret_cast<float *>(smem + LDS_RT);                   // [4][RTH][RTW]
+    const uint4 *wl = reinterpret_cast<const uint4 *>(smem + LDS_RT + LDS_RSUM);  // weight fragments
+    float *tau_s = reinterpret_cast<float *>(smem + LDS_RT + LDS_RSUM + LDS_W);
+    float *tacc_s = tau_s + 64;                                                   // backward: [wave][64]
 
-    const int M = 32 * MT;
+    constexpr int M = 32 * MT;
+    constexpr int FA = MT * 4, FB = 4 * MT;
+    constexpr int NFRAG = (PREC == 0 ? 2 : 1) * (FA + FB);   // bf16 mode stages only the hi fragments
     int bid = blockIdx.x;
     const int txi = bid % p.tilesX; bid /= p.tilesX;
     const int tyi = bid % p.tilesY;
@@ -141,17 +191,23 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
     const int c = lane & 31, h = lane >> 5;
     const size_t HW = (size_t)p.H * p.W;
 
-    // ---- prologue: zero LDS, stage tau and the residual tile (4 row-shifted bf16 hi/lo copies)
+    // ---- prologue: zero LDS, stage weights, tau and the thin tile (4 row-shifted bf16 hi/lo copies)
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(smem);
-        for (int i = tid; i < (LDS_RT + LDS_RSUM) / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
-        if (MODE == MODE_BWD) tacc_s[tid] = 0.0f;                      // 4 x 64 floats
-        else if (tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
+        for (int i = tid; i < (LDS_RT + LDS_RSUM) / 16; i += NT) z4[i] = make_uint4(0, 0, 0, 0);
+        uint4 *wdst = reinterpret_cast<uint4 *>(smem + LDS_RT + LDS_RSUM);
+        if (PREC == 0) {
+            for (int i = tid; i < NFRAG * 64; i += NT) wdst[i] = p.frags[i];
+        } else {                                            // [A hi | B hi] compacted
+            for (int i = tid; i < FA * 64; i += NT) wdst[i] = p.frags[i];
+            for (int i = tid; i < FB * 64; i += NT) wdst[FA * 64 + i] = p.frags[2 * FA * 64 + i];
+        }
+        if (MODE != MODE_BWD && tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
     }
     __syncthreads();
     {
         const float *rimg = p.r + (size_t)n * HW;
-        for (int i = tid; i < RTH * RTW; i += 256) {
+        for (int i = tid; i < RTH * RTW; i += NT) {
             const int yy = i / RTW, xx = i % RTW;
             const int gy = ty0 - HALO + yy, gx = tx0 - HALO + xx;
             float v = 0.0f;
@@ -166,72 +222,56 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
                 }
         }
     }
-
-    // ---- weights: MFMA A operands, resident in registers for the whole tile
-    constexpr int FA = MT * 4, FB = 4 * MT;
-    bf16x8 wAh[MT][4], wAl[MT][4], wBh[2][2 * MT], wBl[2][2 * MT];
-#pragma unroll
-    for (int R = 0; R < MT; ++R)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            wAh[R][ks] = __builtin_bit_cast(bf16x8, p.frags[(size_t)(R * 4 + ks) * 64 + lane]);
-            if (PREC == 0) wAl[R][ks] = __builtin_bit_cast(bf16x8, p.frags[(size_t)(FA + R * 4 + ks) * 64 + lane]);
-        }
-#pragma unroll
-    for (int Rp = 0; Rp < 2; ++Rp)
-#pragma unroll
-        for (int kb = 0; kb < 2 * MT; ++kb) {
-            wBh[Rp][kb] = __builtin_bit_cast(bf16x8, p.frags[(size_t)(2 * FA + Rp * 2 * MT + kb) * 64 + lane]);
-            if (PREC == 0)
-                wBl[Rp][kb] = __builtin_bit_cast(bf16x8, p.frags[(size_t)(2 * FA + FB + Rp * 2 * MT + kb) * 64 + lane]);
-        }
     __syncthreads();
+
+    // fragment offsets inside the LDS weight area
+    constexpr int OFF_AH = 0;
+    constexpr int OFF_AL = FA;                               // split3 only
+    constexpr int OFF_BH = (PREC == 0 ? 2 * FA : FA);
+    constexpr int OFF_BL = 2 * FA + FB;                      // split3 only
+    auto wfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wl[f * 64 + lane]); };
 
     const int xl = wxi * 32 + c;             // tile-local pixel column of this lane
     const int x = tx0 + xl;
-    float *rsum = rsum_all + wid * (RTH * RTW);       // this wave's slab: in-order adds of one wave only
+    float *rsum = rsum_all + ((wxi & 1) + 2 * (wyi & 1)) * SLAB;
     float ring[7][4];                        // row-direction col2im sums for halo rows yl .. yl+6, by (j & 3)
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ring[i][j] = 0.0f;
-    float tsum[MT][16];                      // backward: per-lane partial threshold gradients
-#pragma unroll
-    for (int R = 0; R < MT; ++R)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) tsum[R][v] = 0.0f;
+    float tacc = 0.0f;                       // backward: this lane's share of the threshold gradient
 
-    // per-lane channel offsets of the MFMA C/D layout: register v of tile R is channel
-    // 32R + 8(v>>2) + 4h + (v&3) of pixel column c
-    const size_t lane_base = ((size_t)n * M + 4 * h) * HW + x;
+    // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
     const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
-
-    float zc[MT][16], gc[MT][16];            // current block's fat inputs (base, gate)
-    auto load_block = [&](int b, float (&zz)[MT][16], float (&gg)[MT][16]) {
-        const int y = ty0 + wyi * RB + b;
-        const bool ok = xok && (y < p.H) && (b < RB);
-        const size_t pix = lane_base + (size_t)y * p.W;
-#pragma unroll
-        for (int R = 0; R < MT; ++R)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const size_t idx = pix + (size_t)(32 * R + 8 * (v >> 2) + (v & 3)) * HW;
-                zz[R][v] = (has_base && ok) ? p.zin[idx] : 0.0f;
-                if (MODE == MODE_BWD) gg[R][v] = ok ? p.gate[idx] : 0.0f;
-            }
-    };
-    if (MODE != MODE_FIRST) load_block(0, zc, gc);
+    const size_t img = (size_t)M * HW;
+    const __amdgpu_buffer_rsrc_t rs_in = fat_rsrc(has_base ? p.zin + (size_t)n * img : p.zout, has_base ? img : 0);
+    const __amdgpu_buffer_rsrc_t rs_gate = fat_rsrc(MODE == MODE_BWD ? p.gate + (size_t)n * img : p.zout,
+                                                    MODE == MODE_BWD ? img : 0);
+    const __amdgpu_buffer_rsrc_t rs_out = fat_rsrc(p.zout + (size_t)n * img, img);
+    const int hw4 = (int)HW * 4;
+    const int lane_off = (int)((4 * h) * HW + x) * 4;
 
 #pragma unroll 1
     for (int b = 0; b < RB; ++b) {
         const int yl = wyi * RB + b;         // tile-local image row of this block
         const int y = ty0 + yl;
         const bool valid = xok && (y < p.H);
+        const int voff = valid ? lane_off + y * p.W * 4 : OOB;
 
-        // prefetch the next block's fat inputs (issued before this block's stores)
-        float zn[MT][16], gn[MT][16];
-        if (MODE != MODE_FIRST) load_block(b + 1, zn, gn);
+        // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
+        //    wave on this SIMD) run while they are in flight
+        float zc[MT][16], gc[MT][16];
+        if (MODE != MODE_FIRST) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int soff = (32 * R + 8 * (v >> 2) + (v & 3)) * hw4;
+                    zc[R][v] = buf_ld(rs_in, voff, soff);
+                    if (MODE == MODE_BWD) gc[R][v] = buf_ld(rs_gate, voff, soff);
+                }
+        }
 
         // -- im2col fragments of the thin input: 8 consecutive rows yl..yl+7 of column xl + j
         const int q = b & 3, e = yl - q;     // copy q is shifted up by q rows: 8-byte aligned window
@@ -251,7 +291,9 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
             }
         }
 
-        // -- analysis-like GEMM
+        __builtin_amdgcn_sched_barrier(0);   // phase fences: keep the scheduler from hoisting every LDS
+                                             // weight read of the block to its top (register blow-up)
+        // -- analysis-like GEMM (weights from LDS)
         f32x16 acc[MT];
 #pragma unroll
         for (int R = 0; R < MT; ++R) {
@@ -259,44 +301,43 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 wh = wfrag(OFF_AH + R * 4 + ks);
                 if (PREC == 0) {
-                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wAl[R][ks], rh[ks], acc[R], 0, 0, 0);
-                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wAh[R][ks], rl[ks], acc[R], 0, 0, 0);
+                    const bf16x8 wlo = wfrag(OFF_AL + R * 4 + ks);
+                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, rh[ks], acc[R], 0, 0, 0);
+                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rl[ks], acc[R], 0, 0, 0);
                 }
-                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wAh[R][ks], rh[ks], acc[R], 0, 0, 0);
+                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rh[ks], acc[R], 0, 0, 0);
             }
         }
 
+        __builtin_amdgcn_sched_barrier(0);
         // -- epilogue
-        const size_t pix = lane_base + (size_t)y * p.W;
+        float ts[MT * 16];
 #pragma unroll
         for (int R = 0; R < MT; ++R)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int chl = 32 * R + 8 * (v >> 2) + (v & 3);        // + 4h folded into lane_base
-                const size_t idx = pix + (size_t)chl * HW;
+                const int chl = 32 * R + 8 * (v >> 2) + (v & 3);        // + 4h folded into lane_off
                 float zz;
                 if (MODE == MODE_BWD) {
-                    const float gt = gc[R][v];
+                    const float gt = gc[R][v];                          // 0 for out-of-image lanes
                     zz = gt != 0.0f ? zc[R][v] + acc[R][v] : 0.0f;
-                    tsum[R][v] += gt > 0.0f ? -zz : (gt < 0.0f ? zz : 0.0f);
-                    if (valid) p.zout[idx] = zz;
+                    ts[16 * R + v] = gt > 0.0f ? -zz : (gt < 0.0f ? zz : 0.0f);
                 } else {
                     const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
-                    zz = cdl_shrink(u, tau_s[chl + 4 * h]);
-                    if (valid) p.zout[idx] = zz; else zz = 0.0f;
+                    zz = valid ? cdl_shrink(u, tau_s[chl + 4 * h]) : 0.0f;
                 }
+                buf_st(zz, rs_out, voff, chl * hw4);
                 acc[R][v] = zz;
             }
-        if (MODE != MODE_FIRST) {
-#pragma unroll
-            for (int R = 0; R < MT; ++R)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) { zc[R][v] = zn[R][v]; if (MODE == MODE_BWD) gc[R][v] = gn[R][v]; }
+        if (MODE == MODE_BWD) {
+            tacc += lane_transpose_sum<MT * 16>(ts, c);
+            if (!p.do_synth) continue;
         }
-        if (MODE == MODE_BWD && !p.do_synth) continue;
 
+        __builtin_amdgcn_sched_barrier(0);
         // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand
         f32x16 D[2];
 #pragma unroll
@@ -317,14 +358,17 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
                 }
 #pragma unroll
                 for (int Rp = 0; Rp < 2; ++Rp) {
+                    const bf16x8 wh = wfrag(OFF_BH + Rp * 2 * MT + 2 * R + s);
                     if (PREC == 0) {
-                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wBl[Rp][2 * R + s], zh, D[Rp], 0, 0, 0);
-                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wBh[Rp][2 * R + s], zl, D[Rp], 0, 0, 0);
+                        const bf16x8 wlo = wfrag(OFF_BL + Rp * 2 * MT + 2 * R + s);
+                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, zh, D[Rp], 0, 0, 0);
+                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl, D[Rp], 0, 0, 0);
                     }
-                    D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wBh[Rp][2 * R + s], zh, D[Rp], 0, 0, 0);
+                    D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh, D[Rp], 0, 0, 0);
                 }
             }
 
+        __builtin_amdgcn_sched_barrier(0);
         // -- col2im, row direction: tap row i = 4Rp + (v>>2) of image row y lands on halo row yl + i;
         //    ring[i] collects halo row yl + i, ring[0] is complete after this block: flush and rotate
 #pragma unroll
@@ -350,20 +394,19 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
     }
 
     if (MODE == MODE_BWD) {
-        // threshold-gradient partials: sum over the 32 pixel lanes of each half, then over waves
-#pragma unroll
-        for (int R = 0; R < MT; ++R)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float sv = tsum[R][v];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
-                if (c == 0) tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = sv;
-            }
+        // lane c of each half holds the wave's sum for accumulator index i = c mod (16 MT):
+        // register v = i & 15 of tile R = i >> 4  ->  channel 32R + 8(v>>2) + 4h + (v&3)
+        if (c < MT * 16) {
+            const int R = c >> 4, v = c & 15;
+            tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tacc;
+        }
         __syncthreads();
-        if (tid < M)
-            p.dtau[(size_t)blockIdx.x * M + tid] =
-                (tacc_s[tid] + tacc_s[64 + tid]) + (tacc_s[128 + tid] + tacc_s[192 + tid]);
+        if (tid < M) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += tacc_s[w * 64 + tid];
+            p.dtau[(size_t)blockIdx.x * M + tid] = s;
+        }
         if (!p.do_synth) return;
     }
 
@@ -377,9 +420,9 @@ __global__ __launch_bounds__(256) void k_stage(FusedParams p)
                 if (h == hh && 4 * hh + jl <= 6)
                     atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * hh + jl], ring[i][jl]);
     __syncthreads();
-    float *patch = p.patches + ((size_t)(n * p.tilesY + tyi) * p.tilesX + txi) * (RTH * RTW);
-    for (int i = tid; i < RTH * RTW; i += 256)
-        patch[i] = (rsum_all[i] + rsum_all[RTH * RTW + i]) + (rsum_all[2 * RTH * RTW + i] + rsum_all[3 * RTH * RTW + i]);
+    float *patch = p.patches + ((size_t)(n * p.tilesY + tyi) * p.tilesX + txi) * SLAB;
+    for (int i = tid; i < SLAB; i += NT)
+        patch[i] = (rsum_all[i] + rsum_all[SLAB + i]) + (rsum_all[2 * SLAB + i] + rsum_all[3 * SLAB + i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,7 +449,7 @@ __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patc
             if (tx < 0 || tx >= tilesX) continue;
             const int xx = X - (tx * TW - HALO);
             if (xx < 0 || xx >= RTW) continue;
-            sum += patches[(((size_t)n * tilesY + ty) * tilesX + tx) * (RTH * RTW) + yy * RTW + xx];
+            sum += patches[(((size_t)n * tilesY + ty) * tilesX + tx) * SLAB + yy * RTW + xx];
         }
     }
     sum *= alpha;
@@ -415,22 +458,25 @@ __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patc
     out[i] = sum;
 }
 
-
 // ------------------------------------------------------------------------------------------
 // Filter gradients on the matrix cores.
 //   dw[ch][tap] = sum_px X[ch][px] * im2col(T)[tap][px]      (D = A * B with the PIXEL index as MFMA k)
 // A operand = X[ch][k = 16 pixels of a row]: the fat tensor arrives with lanes = pixels (coalesced),
 // so it is transposed through LDS: each lane stores its channels as packed bf16 into a [pixel][32 ch]
 // image with 64-B rows (8-byte slots XOR-swizzled by (pixel>>1)&7: conflict-free stores) and the
-// fragments come back through ds_read_b64_tr_b16 (conflict-free, see DESIGN.md).
+// fragments come back through ds_read_b64_tr_b16 (conflict-free).
 // B operand = im2col(T)[k = pixel][tap (i,j)] = T[y-3+i][x-3+j .. +7]: 8 consecutive columns of the
 // one-channel halo tile; 4 column-shifted bf16 copies keep every such window 8-byte aligned.
-// Workgroups stride over the 64 x 16 tiles, each wave accumulating all [op][ch][tap] tiles over its
-// own 32 x 8 pixels; waves are then summed through LDS and one partial per workgroup is written.
-constexpr int TROWS = RTH + 1;               // halo rows + the (never used) i = 7 pad row
+// Workgroup = 8 waves: waves 0-3 reduce operator pair 0, waves 4-7 pair 1, each group covering a
+// 64 x 16 pixel tile as 2 x 2 waves of 32 x 8; workgroups stride over the tiles keeping their
+// [ch][tap] accumulators in registers; waves are then summed through LDS in a fixed order and one
+// partial per workgroup is written.
+constexpr int GW_TH = 16;                    // tile rows of the filter-gradient kernel
+constexpr int GW_RTH = GW_TH + 2 * HALO;     // 22
+constexpr int TROWS = GW_RTH + 1;            // halo rows + the (never used) i = 7 pad row
 constexpr int TPITCH = 72;                   // bf16 elements per row of a shifted copy (144 B)
 constexpr int TCOPY = TROWS * TPITCH;
-constexpr int WG_THIN_BYTES = 2 * 2 * 4 * TCOPY * 2;      // [op][hl][shift] copies
+constexpr int WG_THIN_BYTES = 2 * 2 * 4 * TCOPY * 2;      // [op][hl][shift] copies               (52992)
 constexpr int IMG_ELEMS = 32 * 32;           // one [32 px][32 ch] bf16 image (2 KB)
 
 struct WgradParams {
@@ -441,43 +487,41 @@ struct WgradParams {
 };
 
 template <int MT, int PREC>
-__global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
+__global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     __bf16 *thin = reinterpret_cast<__bf16 *>(dsm);                            // [op][hl][s][TCOPY]
-    __bf16 *imgs = reinterpret_cast<__bf16 *>(dsm + WG_THIN_BYTES);            // [wave][op][R][hl][IMG_ELEMS]
+    __bf16 *imgs = reinterpret_cast<__bf16 *>(dsm + WG_THIN_BYTES);            // [wave][R][hl][IMG_ELEMS]
     constexpr int M = 32 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wxi = wid % WX, wyi = wid / WX;
+    const int op = wid >> 2, wq = wid & 3;                                     // operator pair, wave in group
+    const int wxi = wq & 1, wyi = wq >> 1;
     const int c = lane & 31, h = lane >> 5;
     const size_t HW = (size_t)p.H * p.W;
-    __bf16 *wimg = imgs + (size_t)wid * (2 * MT * 2) * IMG_ELEMS;
+    __bf16 *wimg = imgs + (size_t)wid * (MT * 2) * IMG_ELEMS;
+    const bool active = p.X[op] != nullptr;
 
-    f32x16 acc[2][MT][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int op = 0; op < 2; ++op)
+    for (int R = 0; R < MT; ++R)
 #pragma unroll
-        for (int R = 0; R < MT; ++R)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[op][R][tt][v] = 0.0f;
+            for (int v = 0; v < 16; ++v) acc[R][tt][v] = 0.0f;
 
     // zero the thin copies once: pad elements are read (into ignored tap columns) and must stay finite
-    for (int i = tid; i < WG_THIN_BYTES / 16; i += 256) reinterpret_cast<uint4 *>(dsm)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < WG_THIN_BYTES / 16; i += 512) reinterpret_cast<uint4 *>(dsm)[i] = make_uint4(0, 0, 0, 0);
 
     for (int t = blockIdx.x; t < p.numTiles; t += gridDim.x) {
         int bid = t;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
         const int tyi = bid % p.tilesY;
         const int n = bid / p.tilesY;
-        const int tx0 = txi * TW, ty0 = tyi * TH;
+        const int tx0 = txi * TW, ty0 = tyi * GW_TH;
         __syncthreads();                                  // previous tile's readers are done
-#pragma unroll
-        for (int op = 0; op < 2; ++op) {
-            if (!p.X[op]) continue;
+        if (active) {                                     // each group of 256 threads stages its own thin tile
             const float *timg = p.T[op] + (size_t)n * HW;
-            for (int i = tid; i < RTH * RTW; i += 256) {
+            for (int i = tid & 255; i < GW_RTH * RTW; i += 256) {
                 const int yy = i / RTW, xx = i % RTW;
                 const int gy = ty0 - HALO + yy, gx = tx0 - HALO + xx;
                 float v = 0.0f;
@@ -493,6 +537,7 @@ __global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
             }
         }
         __syncthreads();
+        if (!active) continue;
 
         const int x = tx0 + wxi * 32 + c;
         const bool xok = x < p.W;
@@ -500,83 +545,81 @@ __global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
         for (int b = 0; b < RB; ++b) {
             const int yl = wyi * RB + b, y = ty0 + yl;
             const bool valid = xok && y < p.H;
-            // ---- fat operands: registers (lanes = pixels) -> bf16 hi/lo -> transposition images
+            // ---- fat operand: registers (lanes = pixels) -> bf16 hi/lo -> transposition images
+            const __amdgpu_buffer_rsrc_t rs = fat_rsrc(p.X[op] + (size_t)n * M * HW, (size_t)M * HW);
+            const int voff = valid ? (int)((4 * h) * HW + (size_t)y * p.W + x) * 4 : OOB;
+            const int hw4 = (int)HW * 4;
+            float xv[MT][16];
 #pragma unroll
-            for (int op = 0; op < 2; ++op) {
-                if (!p.X[op]) continue;
-                const float *xp = p.X[op] + ((size_t)n * M + 4 * h) * HW + (size_t)y * p.W + x;
+            for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int R = 0; R < MT; ++R)
+                for (int v = 0; v < 16; ++v)
+                    xv[R][v] = buf_ld(rs, voff, (32 * R + 8 * (v >> 2) + (v & 3)) * hw4);
 #pragma unroll
-                    for (int qv = 0; qv < 4; ++qv) {
-                        bf16x4 hi4, lo4;
+            for (int R = 0; R < MT; ++R)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float val = valid ? xp[(size_t)(32 * R + 8 * qv + e) * HW] : 0.0f;
-                            const __bf16 hh = (__bf16)val;
-                            hi4[e] = hh;
-                            lo4[e] = (__bf16)(val - (float)hh);
-                        }
-                        const int slot = (2 * qv + h) ^ ((c >> 1) & 7);      // 8-byte slot of channels 8qv+4h..+3
-                        __bf16 *dst = wimg + (size_t)((op * MT + R) * 2) * IMG_ELEMS + c * 32 + slot * 4;
-                        *reinterpret_cast<bf16x4 *>(dst) = hi4;
-                        if (PREC == 0) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
+                for (int qv = 0; qv < 4; ++qv) {
+                    bf16x4 hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = xv[R][4 * qv + e];
+                        const __bf16 hh = (__bf16)val;
+                        hi4[e] = hh;
+                        lo4[e] = (__bf16)(val - (float)hh);
                     }
-            }
+                    const int slot = (2 * qv + h) ^ ((c >> 1) & 7);      // 8-byte slot of channels 8qv+4h..+3
+                    __bf16 *dst = wimg + (size_t)(R * 2) * IMG_ELEMS + c * 32 + slot * 4;
+                    *reinterpret_cast<bf16x4 *>(dst) = hi4;
+                    if (PREC == 0) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
+                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                // B fragments: tap column of this lane, 8 consecutive pixels 16kk + 8h + (0..7)
+                bf16x8 Bh[2], Bl[2];
 #pragma unroll
-                for (int op = 0; op < 2; ++op) {
-                    if (!p.X[op]) continue;
-                    // B fragments: tap column of this lane, 8 consecutive pixels 16kk + 8h + (0..7)
-                    bf16x8 Bh[2], Bl[2];
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int tap = 32 * tt + c, ti = tap >> 3, tj = tap & 7;
+                    const int e0 = wxi * 32 + 16 * kk + 8 * h + (tj & 4);
+                    const __bf16 *ph = thin + ((op * 2 + 0) * 4 + (tj & 3)) * TCOPY + (yl + ti) * TPITCH + e0;
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ph);
+                    const bf16x4 a1 = *reinterpret_cast<const bf16x4 *>(ph + 4);
+                    Bh[tt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (PREC == 0) {
+                        const __bf16 *pl = ph + 4 * TCOPY;
+                        const bf16x4 b0 = *reinterpret_cast<const bf16x4 *>(pl);
+                        const bf16x4 b1 = *reinterpret_cast<const bf16x4 *>(pl + 4);
+                        Bl[tt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int R = 0; R < MT; ++R) {
+                    // A fragments by transposed reads: lane (i = lane&15 of group g) gets channel
+                    // 16(g&1) + i, pixels 16kk + 8h + 4*half + (0..3)
+                    const int gg = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+                    bf16x4 part[2][2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = 16 * kk + 8 * h + 4 * half + qq;
+                        const int slot = (4 * gg + pp) ^ ((row >> 1) & 7);
+                        const __bf16 *src = wimg + (size_t)(R * 2) * IMG_ELEMS + row * 32 + slot * 4;
+                        part[0][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4 *)(src));
+                        if (PREC == 0)
+                            part[1][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4 *)(src + IMG_ELEMS));
+                    }
+                    const bf16x8 Ah = __builtin_shufflevector(part[0][0], part[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8 Al;
+                    if (PREC == 0) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const int tap = 32 * tt + c, ti = tap >> 3, tj = tap & 7;
-                        const int e0 = wxi * 32 + 16 * kk + 8 * h + (tj & 4);
-                        const __bf16 *ph = thin + ((op * 2 + 0) * 4 + (tj & 3)) * TCOPY + (yl + ti) * TPITCH + e0;
-                        const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ph);
-                        const bf16x4 a1 = *reinterpret_cast<const bf16x4 *>(ph + 4);
-                        Bh[tt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                         if (PREC == 0) {
-                            const __bf16 *pl = ph + 4 * TCOPY;
-                            const bf16x4 b0 = *reinterpret_cast<const bf16x4 *>(pl);
-                            const bf16x4 b1 = *reinterpret_cast<const bf16x4 *>(pl + 4);
-                            Bl[tt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], acc[R][tt], 0, 0, 0);
+                            acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[tt], acc[R][tt], 0, 0, 0);
                         }
-                    }
-#pragma unroll
-                    for (int R = 0; R < MT; ++R) {
-                        // A fragments by transposed reads: lane (i = lane&15 of group g) gets channel
-                        // 16(g&1) + i, pixels 16kk + 8h + 4*half + (0..3)
-                        const int gg = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
-                        bf16x8 Ah, Al;
-                        {
-                            bf16x4 part[2][2];
-#pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                const int row = 16 * kk + 8 * h + 4 * half + qq;
-                                const int slot = (4 * gg + pp) ^ ((row >> 1) & 7);
-                                const __bf16 *src = wimg + (size_t)((op * MT + R) * 2) * IMG_ELEMS + row * 32 + slot * 4;
-                                part[0][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                    (__attribute__((address_space(3))) bf16x4 *)(src));
-                                if (PREC == 0)
-                                    part[1][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                        (__attribute__((address_space(3))) bf16x4 *)(src + IMG_ELEMS));
-                            }
-                            Ah = __builtin_shufflevector(part[0][0], part[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                            if (PREC == 0) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            if (PREC == 0) {
-                                acc[op][R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], acc[op][R][tt], 0, 0, 0);
-                                acc[op][R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[tt], acc[op][R][tt], 0, 0, 0);
-                            }
-                            acc[op][R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[tt], acc[op][R][tt], 0, 0, 0);
-                        }
+                        acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[tt], acc[R][tt], 0, 0, 0);
                     }
                 }
             }
@@ -585,29 +628,27 @@ __global__ __launch_bounds__(256) void k_wgrad2d(WgradParams p)
         }
     }
 
-    // ---- sum the four waves through LDS and write this workgroup's partial
-    // (wave 0 stores, waves 1..3 add in turn: fixed order, every lane owns its own words)
+    // ---- sum the four waves of each group through LDS (wave 0 stores, 1..3 add in turn: fixed
+    //      order, every lane owns its own words) and write this workgroup's partial
     float *red = reinterpret_cast<float *>(dsm);                               // [2][M][64]
     for (int w = 0; w < 4; ++w) {
         __syncthreads();
-        if (wid == w) {
+        if (wq == w) {
 #pragma unroll
-            for (int op = 0; op < 2; ++op)
+            for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int R = 0; R < MT; ++R)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int ch = 32 * R + (v & 3) + 8 * (v >> 2) + 4 * h;
-                            float *dstw = &red[(op * M + ch) * 64 + 32 * tt + c];
-                            *dstw = (w == 0 ? 0.0f : *dstw) + acc[op][R][tt][v];
-                        }
+                    for (int v = 0; v < 16; ++v) {
+                        const int ch = 32 * R + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        float *dstw = &red[(op * M + ch) * 64 + 32 * tt + c];
+                        *dstw = (w == 0 ? 0.0f : *dstw) + acc[R][tt][v];
+                    }
         }
     }
     __syncthreads();
     float *dst = p.partial + (size_t)blockIdx.x * 2 * M * 64;
-    for (int i = tid; i < 2 * M * 64; i += 256) dst[i] = red[i];
+    for (int i = tid; i < 2 * M * 64; i += 512) dst[i] = red[i];
 }
 
 // dw[ch][i'][j'] = alpha * sum_g partial[g][op][ch][8(i'+off) + (j'+off)].  32 outputs per workgroup,
@@ -677,17 +718,34 @@ inline bool fused_shape_ok(const cdl_geom *g)
     if (g->C != 1 || g->D != 1 || g->Pd != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
     if (g->Ph != g->Pw || g->Ph > 7 || (g->Ph & 1) == 0 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
     if (g->M != 32 && g->M != 64) return false;
+    if ((size_t)g->M * g->H * g->W * 4 >= ((size_t)1 << 31)) return false;   // per-image buffer descriptor range
     return true;
+}
+
+inline int tiles_x(const cdl_geom *g) { return (g->W + TW - 1) / TW; }
+inline int tiles_y(const cdl_geom *g) { return (g->H + TH - 1) / TH; }
+
+template <int MT, int PREC, int MODE>
+int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
+{
+    static bool attr_done = false;               // idempotent; a race only repeats the call
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_stage<MT, PREC, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STAGE);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_stage<MT, PREC, MODE><<<grid, NT, LDS_STAGE, st>>>(p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
 }
 
 template <int MT, int PREC>
 int launch_stage(const FusedParams &p, int mode, dim3 grid, hipStream_t st)
 {
-    if (mode == MODE_FWD) k_stage<MT, PREC, MODE_FWD><<<grid, 256, 0, st>>>(p);
-    else if (mode == MODE_FIRST) k_stage<MT, PREC, MODE_FIRST><<<grid, 256, 0, st>>>(p);
-    else k_stage<MT, PREC, MODE_BWD><<<grid, 256, 0, st>>>(p);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(int)e;
+    if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD>(p, grid, st);
+    if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST>(p, grid, st);
+    return launch_stage_one<MT, PREC, MODE_BWD>(p, grid, st);
 }
 
 int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, int precision, hipStream_t st)
@@ -695,6 +753,28 @@ int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, int precis
     dim3 grid((unsigned)((size_t)p.N * p.tilesX * p.tilesY));
     if (g->M == 64) return precision == 0 ? launch_stage<2, 0>(p, mode, grid, st) : launch_stage<2, 1>(p, mode, grid, st);
     return precision == 0 ? launch_stage<1, 0>(p, mode, grid, st) : launch_stage<1, 1>(p, mode, grid, st);
+}
+
+int wgrad_grid(const cdl_geom *g)
+{
+    const size_t tiles = (size_t)g->N * tiles_x(g) * ((g->H + GW_TH - 1) / GW_TH);
+    return (int)(tiles < 512 ? tiles : 512);
+}
+
+template <int MT, int PREC>
+int launch_wgrad(const WgradParams &p, int G, hipStream_t st)
+{
+    const size_t lds = (size_t)WG_THIN_BYTES + (size_t)8 * MT * 2 * IMG_ELEMS * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_wgrad2d<MT, PREC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_wgrad2d<MT, PREC><<<G, 512, lds, st>>>(p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
 }
 
 }  // namespace
@@ -708,8 +788,13 @@ size_t cdl_fused2d_frag_bytes(int M) { return (size_t)2 * (M / 32) * 8 * 64 * 16
 size_t cdl_fused2d_patch_floats(const cdl_geom *g)
 {
     if (!fused_shape_ok(g)) return 0;
-    const size_t tilesX = (g->W + TW - 1) / TW, tilesY = (g->H + TH - 1) / TH;
-    return (size_t)g->N * tilesX * tilesY * RTH * RTW;
+    return (size_t)g->N * tiles_x(g) * tiles_y(g) * SLAB;
+}
+
+size_t cdl_fused2d_tiles(const cdl_geom *g)
+{
+    if (!fused_shape_ok(g)) return 0;
+    return (size_t)g->N * tiles_x(g) * tiles_y(g);
 }
 
 int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P, void *stream)
@@ -733,14 +818,8 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = sgn; p.do_synth = 1;
     p.N = g->N; p.H = g->H; p.W = g->W;
-    p.tilesX = (g->W + TW - 1) / TW; p.tilesY = (g->H + TH - 1) / TH;
+    p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, precision, S(stream));
-}
-
-size_t cdl_fused2d_tiles(const cdl_geom *g)
-{
-    if (!fused_shape_ok(g)) return 0;
-    return (size_t)g->N * ((g->W + TW - 1) / TW) * ((g->H + TH - 1) / TH);
 }
 
 int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const float *gate,
@@ -756,7 +835,7 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0;
     p.N = g->N; p.H = g->H; p.W = g->W;
-    p.tilesX = (g->W + TW - 1) / TW; p.tilesY = (g->H + TH - 1) / TH;
+    p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, MODE_BWD, precision, S(stream));
 }
 
@@ -765,17 +844,9 @@ int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const 
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
-    const int per_img = ((g->W + TW - 1) / TW) * ((g->H + TH - 1) / TH);
-    k_dtau_reduce<<<1, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, per_img, g->M);
+    k_dtau_reduce<<<1, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, tiles_x(g) * tiles_y(g), g->M);
     CDL_LAUNCH_CHECK();
     return 0;
-}
-
-
-static int wgrad_grid(const cdl_geom *g)
-{
-    const size_t tiles = (size_t)g->N * ((g->W + TW - 1) / TW) * ((g->H + TH - 1) / TH);
-    return (int)(tiles < 512 ? tiles : 512);
 }
 
 size_t cdl_fused2d_wgrad_workspace_floats(const cdl_geom *g)
@@ -796,27 +867,16 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     p.X[0] = X0; p.T[0] = T0; p.X[1] = X1; p.T[1] = T1;
     p.partial = workspace;
     p.N = g->N; p.H = g->H; p.W = g->W;
-    p.tilesX = (g->W + TW - 1) / TW; p.tilesY = (g->H + TH - 1) / TH;
+    p.tilesX = tiles_x(g); p.tilesY = (g->H + GW_TH - 1) / GW_TH;
     p.numTiles = p.N * p.tilesX * p.tilesY;
     const int G = wgrad_grid(g);
-    const int MT = g->M / 32;
-    const size_t lds = (size_t)WG_THIN_BYTES + (size_t)4 * 2 * MT * 2 * IMG_ELEMS * 2;
-    const void *fn;
-    if (MT == 2) fn = precision == 0 ? (const void *)k_wgrad2d<2, 0> : (const void *)k_wgrad2d<2, 1>;
-    else fn = precision == 0 ? (const void *)k_wgrad2d<1, 0> : (const void *)k_wgrad2d<1, 1>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    if (MT == 2) {
-        if (precision == 0) k_wgrad2d<2, 0><<<G, 256, lds, S(stream)>>>(p);
-        else k_wgrad2d<2, 1><<<G, 256, lds, S(stream)>>>(p);
-    } else {
-        if (precision == 0) k_wgrad2d<1, 0><<<G, 256, lds, S(stream)>>>(p);
-        else k_wgrad2d<1, 1><<<G, 256, lds, S(stream)>>>(p);
-    }
-    CDL_LAUNCH_CHECK();
+    int rc;
+    if (g->M == 64) rc = precision == 0 ? launch_wgrad<2, 0>(p, G, S(stream)) : launch_wgrad<2, 1>(p, G, S(stream));
+    else rc = precision == 0 ? launch_wgrad<1, 0>(p, G, S(stream)) : launch_wgrad<1, 1>(p, G, S(stream));
+    if (rc) return rc;
     const int total = 2 * g->M * g->Ph * g->Pw;
     k_wgrad_reduce<<<(total + 31) / 32, 256, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
-                                                               X1 ? dw1 : nullptr, alpha1, g->M, g->Ph);
+                                                             X1 ? dw1 : nullptr, alpha1, g->M, g->Ph);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -828,7 +888,7 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
     if (!patches || !out) return CDL_EINVAL;
     const size_t total = (size_t)g->N * g->H * g->W;
     k_assemble<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(
-        patches, mask, sub, alpha, out, g->N, g->H, g->W, (g->W + TW - 1) / TW, (g->H + TH - 1) / TH);
+        patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
     CDL_LAUNCH_CHECK();
     return 0;
 }

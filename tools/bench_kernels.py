@@ -44,22 +44,33 @@ def main():
     ms = ev(lambda: o.fused_iter(g, r, None, tau, frags, 1.0, patches, "split3", out=out))
     rows.append({"kernel": "k_iter_fwd[split3,first]", "ms": ms, "alg_bytes": fat + 2 * th,
                  "GBps": (fat + 2 * th) / ms / 1e6})
-    ms = ev(lambda: o.fused_assemble(g, patches, None, r, out=thin))
+    gup = torch.randn_like(z)
+    dtp = torch.empty((o.fused_tiles(g), M), device=dev)
+    ws = o.fused_wgrad_workspace(g, dev)
+    for prec in ("split3", "bf16"):
+        ms = ev(lambda: o.fused_stage_bwd(g, r, gup, z, frags, patches, dtp, True, prec, out=out))
+        rows.append({"kernel": f"k_stage<BWD>[{prec}]", "ms": ms, "alg_bytes": 3 * fat + 2 * th,
+                     "GBps": (3 * fat + 2 * th) / ms / 1e6})
+        ms = ev(lambda: o.fused_wgrad(g, ws, gup, r, -1.0, z, r, 1.0, prec))
+        rows.append({"kernel": f"k_wgrad2d[{prec}]", "ms": ms, "alg_bytes": 2 * fat + 2 * th,
+                     "GBps": (2 * fat + 2 * th) / ms / 1e6})
+    dt = torch.zeros(2, M, device=dev)
+    ms = ev(lambda: o.fused_dtau_reduce(g, dtp, None, dt))
+    rows.append({"kernel": "k_dtau_reduce", "ms": ms})
+    ms = ev(lambda: o.fused_assemble(g, patches, None, r, 1.0, out=thin))
     rows.append({"kernel": "k_assemble", "ms": ms, "alg_bytes": 3 * th, "GBps": 3 * th / ms / 1e6})
     ms = ev(lambda: o.fused_prep(w, w))
     rows.append({"kernel": "k_prep", "ms": ms})
     ms = ev(lambda: out.copy_(z))
     rows.append({"kernel": "torch copy fat (HBM yardstick)", "ms": ms, "alg_bytes": 2 * fat,
                  "GBps": 2 * fat / ms / 1e6})
-    if os.environ.get("BK_GENERIC", "1") == "1":
+    if os.environ.get("BK_GENERIC", "0") == "1":
         ms = ev(lambda: o.analysis(g, r, w, -1.0, z, None, tau, out=out), 3)
         rows.append({"kernel": "generic k_analysis", "ms": ms, "GBps": (2 * fat + th) / ms / 1e6})
         ms = ev(lambda: o.synthesis(g, z, w, 1.0, None, None, r, out=thin), 3)
         rows.append({"kernel": "generic k_synthesis", "ms": ms, "GBps": (fat + 2 * th) / ms / 1e6})
-        gup = torch.randn_like(z)
         ms = ev(lambda: o.wgrad(g, gup, r, -1.0, gate=z), 2)
         rows.append({"kernel": "generic k_wgrad(gated)", "ms": ms})
-        dt = torch.zeros(2, M, device=dev)
         ms = ev(lambda: o.tau_grad(g, gup, z, None, dt), 3)
         rows.append({"kernel": "generic k_tau", "ms": ms, "GBps": 2 * fat / ms / 1e6})
     for row in rows:
