@@ -28,6 +28,7 @@
 // workgroup writes its (32+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
 // patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
+#include <cstdlib>
 #include "cdl_common.h"
 
 namespace {
@@ -66,6 +67,8 @@ struct FusedParams {
     float *patches;          // (N,tilesY,tilesX,RTH,RTW)
     float sgn;               // u = zin + sgn * acc
     int do_synth;            // 0: skip the synthesis-like half (last backward stage)
+    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis,
+                             // 4 no analysis MFMAs, 8 no thin staging, 16 no fat loads; results are wrong
     int N, H, W, tilesX, tilesY;
 };
 
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         if (MODE != MODE_BWD && tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
     }
     __syncthreads();
-    {
+    if (!(p.dbg & 8)) {
         const float *rimg = p.r + (size_t)n * HW;
         for (int i = tid; i < RTH * RTW; i += NT) {
             const int yy = i / RTW, xx = i % RTW;
@@ -239,7 +242,9 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ring[i][j] = 0.0f;
-    float tacc = 0.0f;                       // backward: this lane's share of the threshold gradient
+    float tsum[MT * 16];                     // backward: per-lane partial threshold gradients
+#pragma unroll
+    for (int i = 0; i < MT * 16; ++i) tsum[i] = 0.0f;
 
     // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
@@ -262,7 +267,12 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
         float zc[MT][16], gc[MT][16];
-        if (MODE != MODE_FIRST) {
+        if (MODE != MODE_FIRST && (p.dbg & 16)) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { zc[R][v] = 0.25f; gc[R][v] = 1.0f; }
+        } else if (MODE != MODE_FIRST) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         for (int R = 0; R < MT; ++R) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+            if (p.dbg & 4) { acc[R][0] = (float)rh[0][0] + (float)rl[1][1]; continue; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 wh = wfrag(OFF_AH + R * 4 + ks);
@@ -313,7 +324,6 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
         __builtin_amdgcn_sched_barrier(0);
         // -- epilogue
-        float ts[MT * 16];
 #pragma unroll
         for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -323,19 +333,17 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 if (MODE == MODE_BWD) {
                     const float gt = gc[R][v];                          // 0 for out-of-image lanes
                     zz = gt != 0.0f ? zc[R][v] + acc[R][v] : 0.0f;
-                    ts[16 * R + v] = gt > 0.0f ? -zz : (gt < 0.0f ? zz : 0.0f);
+                    tsum[16 * R + v] += gt > 0.0f ? -zz : (gt < 0.0f ? zz : 0.0f);
                 } else {
                     const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
                     zz = valid ? cdl_shrink(u, tau_s[chl + 4 * h]) : 0.0f;
                 }
-                buf_st(zz, rs_out, voff, chl * hw4);
+                if (!(p.dbg & 1)) buf_st(zz, rs_out, voff, chl * hw4);
                 acc[R][v] = zz;
             }
-        if (MODE == MODE_BWD) {
-            tacc += lane_transpose_sum<MT * 16>(ts, c);
-            if (!p.do_synth) continue;
-        }
+        if (MODE == MODE_BWD && !p.do_synth) continue;
+        if (p.dbg & 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
         __builtin_amdgcn_sched_barrier(0);
         // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     if (MODE == MODE_BWD) {
         // lane c of each half holds the wave's sum for accumulator index i = c mod (16 MT):
         // register v = i & 15 of tile R = i >> 4  ->  channel 32R + 8(v>>2) + 4h + (v&3)
+        const float tacc = lane_transpose_sum<MT * 16>(tsum, c);
         if (c < MT * 16) {
             const int R = c >> 4, v = c & 15;
             tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tacc;
@@ -722,6 +731,13 @@ inline bool fused_shape_ok(const cdl_geom *g)
     return true;
 }
 
+inline int debug_flags()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("CDL_FUSED_DEBUG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 inline int tiles_x(const cdl_geom *g) { return (g->W + TW - 1) / TW; }
 inline int tiles_y(const cdl_geom *g) { return (g->H + TH - 1) / TH; }
 
@@ -816,7 +832,7 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     FusedParams p = {};
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau;
     p.frags = reinterpret_cast<const uint4 *>(frags);
-    p.patches = patches; p.sgn = sgn; p.do_synth = 1;
+    p.patches = patches; p.sgn = sgn; p.do_synth = 1; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, precision, S(stream));
@@ -833,7 +849,7 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     FusedParams p = {};
     p.r = thin; p.zin = base; p.gate = gate; p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
-    p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0;
+    p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, MODE_BWD, precision, S(stream));
