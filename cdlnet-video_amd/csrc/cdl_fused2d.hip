@@ -184,17 +184,14 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     constexpr int M = 32 * MT;
     constexpr int FA = MT * 4, FB = 4 * MT;
     constexpr int NFRAG = (PREC == 0 ? 2 : 1) * (FA + FB);   // bf16 mode stages only the hi fragments
-    int bid = blockIdx.x;
-    const int txi = bid % p.tilesX; bid /= p.tilesX;
-    const int tyi = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int tx0 = txi * TW, ty0 = tyi * TH;
+    constexpr int NSTG = (RTH * RTW + NT - 1) / NT;          // thin-tile elements staged per thread
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wxi = wid % WX, wyi = wid / WX;
     const int c = lane & 31, h = lane >> 5;
     const size_t HW = (size_t)p.H * p.W;
+    const int numTiles = p.N * p.tilesY * p.tilesX;
 
-    // ---- prologue: zero LDS, stage weights, tau and the thin tile (4 row-shifted bf16 hi/lo copies)
+    // ---- once per workgroup: zero LDS, weight fragments -> LDS
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < (LDS_RT + LDS_RSUM) / 16; i += NT) z4[i] = make_uint4(0, 0, 0, 0);
@@ -205,18 +202,36 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             for (int i = tid; i < FA * 64; i += NT) wdst[i] = p.frags[i];
             for (int i = tid; i < FB * 64; i += NT) wdst[FA * 64 + i] = p.frags[2 * FA * 64 + i];
         }
-        if (MODE != MODE_BWD && tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
     }
-    __syncthreads();
-    if (!(p.dbg & 8)) {
+    // thin-tile staging: registers first (so the next tile's loads fly during this tile's GEMMs), then
+    // 4 row-shifted bf16 hi/lo copies in LDS.  Every in-tile word is rewritten per tile (zeros outside
+    // the image); the pad words stay zero from the pass above.
+    float stg[NSTG];
+    auto stage_load = [&](int t) {
+        int bid = t;
+        const int txi = bid % p.tilesX; bid /= p.tilesX;
+        const int tyi = bid % p.tilesY;
+        const int n = bid / p.tilesY;
         const float *rimg = p.r + (size_t)n * HW;
-        for (int i = tid; i < RTH * RTW; i += NT) {
+#pragma unroll
+        for (int k = 0; k < NSTG; ++k) {
+            const int i = tid + k * NT;
             const int yy = i / RTW, xx = i % RTW;
-            const int gy = ty0 - HALO + yy, gx = tx0 - HALO + xx;
+            const int gy = tyi * TH - HALO + yy, gx = txi * TW - HALO + xx;
             float v = 0.0f;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = rimg[(size_t)gy * p.W + gx];
-            const __bf16 hh = (__bf16)v;
-            const __bf16 ll = (__bf16)(v - (float)hh);
+            if (i < RTH * RTW && t < numTiles && !(p.dbg & 8) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v = rimg[(size_t)gy * p.W + gx];
+            stg[k] = v;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < NSTG; ++k) {
+            const int i = tid + k * NT;
+            if (i >= RTH * RTW) continue;
+            const int yy = i / RTW, xx = i % RTW;
+            const __bf16 hh = (__bf16)stg[k];
+            const __bf16 ll = (__bf16)(stg[k] - (float)hh);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (yy - q >= 0) {
@@ -224,8 +239,10 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     if (PREC == 0) rt[(1 * 4 + q) * COPY + xx * PITCH + (yy - q)] = ll;
                 }
         }
-    }
-    __syncthreads();
+    };
+    stage_load(blockIdx.x);
+    __syncthreads();                                        // zero pass done before the first fill
+    stage_store();
 
     // fragment offsets inside the LDS weight area
     constexpr int OFF_AH = 0;
@@ -235,8 +252,23 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     auto wfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wl[f * 64 + lane]); };
 
     const int xl = wxi * 32 + c;             // tile-local pixel column of this lane
-    const int x = tx0 + xl;
     float *rsum = rsum_all + ((wxi & 1) + 2 * (wyi & 1)) * SLAB;
+    const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
+    const size_t img = (size_t)M * HW;
+    const int hw4 = (int)HW * 4;
+
+#pragma unroll 1
+    for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
+    int bid = t;
+    const int txi = bid % p.tilesX; bid /= p.tilesX;
+    const int tyi = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int tx0 = txi * TW, ty0 = tyi * TH;
+    const int x = tx0 + xl;
+    if (MODE != MODE_BWD && tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
+    __syncthreads();                         // thin copies + tau of this tile are in place
+    stage_load(t + gridDim.x);               // next tile's thin loads fly during the GEMMs below
+
     float ring[7][4];                        // row-direction col2im sums for halo rows yl .. yl+6, by (j & 3)
 #pragma unroll
     for (int i = 0; i < 7; ++i)
@@ -248,13 +280,10 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
     // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
-    const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
-    const size_t img = (size_t)M * HW;
     const __amdgpu_buffer_rsrc_t rs_in = fat_rsrc(has_base ? p.zin + (size_t)n * img : p.zout, has_base ? img : 0);
     const __amdgpu_buffer_rsrc_t rs_gate = fat_rsrc(MODE == MODE_BWD ? p.gate + (size_t)n * img : p.zout,
                                                     MODE == MODE_BWD ? img : 0);
     const __amdgpu_buffer_rsrc_t rs_out = fat_rsrc(p.zout + (size_t)n * img, img);
-    const int hw4 = (int)HW * 4;
     const int lane_off = (int)((4 * h) * HW + x) * 4;
 
 #pragma unroll 1
@@ -401,6 +430,17 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         for (int jl = 0; jl < 4; ++jl) ring[6][jl] = 0.0f;
     }
 
+    // ---- the 6 halo rows below the wave's last image row are still in the ring
+    if (MODE != MODE_BWD || p.do_synth) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int jl = 0; jl < 4; ++jl)
+                    if (h == hh && 4 * hh + jl <= 6)
+                        atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * hh + jl], ring[i][jl]);
+    }
     if (MODE == MODE_BWD) {
         // lane c of each half holds the wave's sum for accumulator index i = c mod (16 MT):
         // register v = i & 15 of tile R = i >> 4  ->  channel 32R + 8(v>>2) + 4h + (v&3)
@@ -409,29 +449,23 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             const int R = c >> 4, v = c & 15;
             tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tacc;
         }
-        __syncthreads();
-        if (tid < M) {
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) s += tacc_s[w * 64 + tid];
-            p.dtau[(size_t)blockIdx.x * M + tid] = s;
-        }
-        if (!p.do_synth) return;
     }
-
-    // ---- the 6 halo rows below the wave's last image row are still in the ring
+    __syncthreads();                         // every wave is done with the thin copies and the slabs
+    if (MODE == MODE_BWD && tid < M) {
+        float sacc = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int jl = 0; jl < 4; ++jl)
-                if (h == hh && 4 * hh + jl <= 6)
-                    atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * hh + jl], ring[i][jl]);
-    __syncthreads();
-    float *patch = p.patches + ((size_t)(n * p.tilesY + tyi) * p.tilesX + txi) * SLAB;
-    for (int i = tid; i < SLAB; i += NT)
-        patch[i] = (rsum_all[i] + rsum_all[SLAB + i]) + (rsum_all[2 * SLAB + i] + rsum_all[3 * SLAB + i]);
+        for (int w = 0; w < NW; ++w) sacc += tacc_s[w * 64 + tid];
+        p.dtau[(size_t)t * M + tid] = sacc;
+    }
+    if (MODE != MODE_BWD || p.do_synth) {    // patch out (fixed slab order), slabs re-zeroed for the next tile
+        float *patch = p.patches + (size_t)t * SLAB;
+        for (int i = tid; i < SLAB; i += NT) {
+            patch[i] = (rsum_all[i] + rsum_all[SLAB + i]) + (rsum_all[2 * SLAB + i] + rsum_all[3 * SLAB + i]);
+            rsum_all[i] = 0.0f; rsum_all[SLAB + i] = 0.0f; rsum_all[2 * SLAB + i] = 0.0f; rsum_all[3 * SLAB + i] = 0.0f;
+        }
+    }
+    stage_store();                           // next tile's thin copies (registers loaded above)
+    }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------
@@ -764,9 +798,26 @@ int launch_stage(const FusedParams &p, int mode, dim3 grid, hipStream_t st)
     return launch_stage_one<MT, PREC, MODE_BWD>(p, grid, st);
 }
 
+inline int cu_count()
+{
+    static int n = 0;                            // one GPU per process (one rank per GPU)
+    if (n <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, int precision, hipStream_t st)
 {
-    dim3 grid((unsigned)((size_t)p.N * p.tilesX * p.tilesY));
+    // persistent workgroups: one per CU (128 KB of LDS each), striding over the tiles
+    const size_t tiles = (size_t)p.N * p.tilesX * p.tilesY;
+    const size_t cus = (size_t)cu_count();
+    dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     if (g->M == 64) return precision == 0 ? launch_stage<2, 0>(p, mode, grid, st) : launch_stage<2, 1>(p, mode, grid, st);
     return precision == 0 ? launch_stage<1, 0>(p, mode, grid, st) : launch_stage<1, 1>(p, mode, grid, st);
 }
