@@ -67,7 +67,7 @@ struct FusedParams {
     float *patches;          // (N,tilesY,tilesX,RTH,RTW)
     float sgn;               // u = zin + sgn * acc
     int do_synth;            // 0: skip the synthesis-like half (last backward stage)
-    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis,
+    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis, 32 no LDS adds, 64 no ST,
                              // 4 no analysis MFMAs, 8 no thin staging, 16 no fat loads; results are wrong
     int N, H, W, tilesX, tilesY;
 };
@@ -149,23 +149,66 @@ __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, int vo
 constexpr int OOB = 0x7fff0000;              // byte offset beyond any descriptor range
 
 // Sum over the 32 pixel lanes of each half-wave of N per-lane values, leaving total #i on lane
-// (c with c mod N == i): a halving butterfly, N-1 exchanges instead of 5N.
+// (c with c mod N == i): a halving butterfly, N-1 exchanges instead of 5N.  Template recursion keeps
+// every register index static.
 template <int N>
-__device__ __forceinline__ float lane_transpose_sum(float (&v)[N], int c)
-{
-#pragma unroll
-    for (int n = N / 2, bit = (N == 32 ? 16 : 8); n >= 1; n >>= 1, bit >>= 1) {
-        const bool up = (c & bit) != 0;
+struct LaneTransposeSum {
+    static __device__ __forceinline__ float run(const float (&v)[N], int c)
+    {
+        constexpr int n = N / 2;
+        const bool up = (c & n) != 0;
+        float w[n];
 #pragma unroll
         for (int k = 0; k < n; ++k) {
             const float keep = up ? v[k + n] : v[k];
             const float send = up ? v[k] : v[k + n];
-            v[k] = keep + __shfl_xor(send, bit, 64);
+            w[k] = keep + __shfl_xor(send, n, 64);
         }
+        return LaneTransposeSum<n>::run(w, c);
     }
-    float r = v[0];
+};
+template <>
+struct LaneTransposeSum<1> {
+    static __device__ __forceinline__ float run(const float (&v)[1], int) { return v[0]; }
+};
+template <int N>
+__device__ __forceinline__ float lane_transpose_sum(const float (&v)[N], int c)
+{
+    float r = LaneTransposeSum<N>::run(v, c);
     if (N == 16) r += __shfl_xor(r, 16, 64);           // lanes c and c^16 hold halves of the same index
     return r;
+}
+
+// lane i <- lane i-1 over the whole wave (lane 0 <- 0): one DPP modifier on the consuming add
+__device__ __forceinline__ float wave_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+// lanes 0..31 receive the value held by lanes 32..63
+__device__ __forceinline__ float upper_half_to_lower(float v)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, pr[1]);
+}
+// col2im, column direction, for one halo row: lane (c, h) holds tap columns j = 4h + (0..3) of pixel
+// column c; returns on lane L (0..37) the sum over j of the value of column L - j.  The upper half's
+// taps are first moved onto the lower lanes, then a 6-step Horner chain of DPP wave shifts lets the
+// terms that leave column 31 collect on lanes 32..37 (the overlap with the next wave's columns).
+__device__ __forceinline__ float col2im_row(const float (&rv)[4], int h)
+{
+    const float r4 = upper_half_to_lower(rv[0]);
+    const float r5 = upper_half_to_lower(rv[1]);
+    const float r6 = upper_half_to_lower(rv[2]);
+    const bool lo = h == 0;
+    float s = lo ? r6 : 0.0f;
+    s = wave_shr1(s) + (lo ? r5 : 0.0f);
+    s = wave_shr1(s) + (lo ? r4 : 0.0f);
+    s = wave_shr1(s) + (lo ? rv[3] : 0.0f);
+    s = wave_shr1(s) + (lo ? rv[2] : 0.0f);
+    s = wave_shr1(s) + (lo ? rv[1] : 0.0f);
+    s = wave_shr1(s) + (lo ? rv[0] : 0.0f);
+    return s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     const int x = tx0 + xl;
     if (MODE != MODE_BWD && tid < M) tau_s[tid] = p.tau[(size_t)n * M + tid];
     __syncthreads();                         // thin copies + tau of this tile are in place
-    stage_load(t + gridDim.x);               // next tile's thin loads fly during the GEMMs below
+    if (MODE != MODE_BWD) stage_load(t + gridDim.x);   // next tile's thin loads fly during the GEMMs below
 
     float ring[7][4];                        // row-direction col2im sums for halo rows yl .. yl+6, by (j & 3)
 #pragma unroll
@@ -277,6 +320,17 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     float tsum[MT * 16];                     // backward: per-lane partial threshold gradients
 #pragma unroll
     for (int i = 0; i < MT * 16; ++i) tsum[i] = 0.0f;
+    float taur[MT * 16];                     // forward: this lane's 16 MT thresholds
+    if (MODE != MODE_BWD) {
+#pragma unroll
+        for (int R = 0; R < MT; ++R)
+#pragma unroll
+            for (int qv = 0; qv < 4; ++qv) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&tau_s[32 * R + 8 * qv + 4 * h]);
+                taur[16 * R + 4 * qv + 0] = t4.x; taur[16 * R + 4 * qv + 1] = t4.y;
+                taur[16 * R + 4 * qv + 2] = t4.z; taur[16 * R + 4 * qv + 3] = t4.w;
+            }
+    }
 
     // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
@@ -292,6 +346,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         const int y = ty0 + yl;
         const bool valid = xok && (y < p.H);
         const int voff = valid ? lane_off + y * p.W * 4 : OOB;
+        const int voff_st = (p.dbg & 1) ? OOB : voff;
 
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
@@ -349,6 +404,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 }
                 acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rh[ks], acc[R], 0, 0, 0);
             }
+            if (MODE == MODE_BWD) __builtin_amdgcn_sched_barrier(0);     // bound the weight-read hoisting
         }
 
         __builtin_amdgcn_sched_barrier(0);
@@ -366,9 +422,9 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 } else {
                     const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
-                    zz = valid ? cdl_shrink(u, tau_s[chl + 4 * h]) : 0.0f;
+                    zz = (p.dbg & 64) ? u : (valid ? cdl_shrink(u, taur[16 * R + v]) : 0.0f);
                 }
-                if (!(p.dbg & 1)) buf_st(zz, rs_out, voff, chl * hw4);
+                buf_st(zz, rs_out, voff_st, chl * hw4);
                 acc[R][v] = zz;
             }
         if (MODE == MODE_BWD && !p.do_synth) continue;
@@ -415,13 +471,13 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 const int i = 4 * Rp + (v >> 2);
                 if (i <= 6) ring[i][v & 3] += D[Rp][v];
             }
-        // (the two lane halves overlap in their target columns: one half per instruction keeps every
-        //  add of an instruction on a distinct word, so the summation order is fixed)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int jl = 0; jl < 4; ++jl)
-                if (h == hh && 4 * hh + jl <= 6) atomicAdd(&rsum[yl * RTW + xl + 4 * hh + jl], ring[0][jl]);
+        // Column direction in registers (col2im_row), then ONE plain LDS store per lane: within a slab
+        // every word is written by exactly one wave, once per tile (slabs are zeroed between tiles),
+        // so no atomics and no read-modify-write are needed and the result is order-independent.
+        {
+            const float cs = col2im_row(ring[0], h);
+            if (lane < 38 && !(p.dbg & 32)) rsum[yl * RTW + 32 * wxi + lane] = cs;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -433,24 +489,22 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     // ---- the 6 halo rows below the wave's last image row are still in the ring
     if (MODE != MODE_BWD || p.do_synth) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int jl = 0; jl < 4; ++jl)
-                    if (h == hh && 4 * hh + jl <= 6)
-                        atomicAdd(&rsum[(wyi * RB + RB + i) * RTW + xl + 4 * hh + jl], ring[i][jl]);
+        for (int i = 0; i < 6; ++i) {
+            const float cs = col2im_row(ring[i], h);
+            if (lane < 38 && !(p.dbg & 32)) rsum[(wyi * RB + RB + i) * RTW + 32 * wxi + lane] = cs;
+        }
     }
     if (MODE == MODE_BWD) {
         // lane c of each half holds the wave's sum for accumulator index i = c mod (16 MT):
         // register v = i & 15 of tile R = i >> 4  ->  channel 32R + 8(v>>2) + 4h + (v&3)
-        const float tacc = lane_transpose_sum<MT * 16>(tsum, c);
+        const float tacc = lane_transpose_sum(tsum, c);
         if (c < MT * 16) {
             const int R = c >> 4, v = c & 15;
             tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tacc;
         }
     }
     __syncthreads();                         // every wave is done with the thin copies and the slabs
+    if (MODE == MODE_BWD) stage_load(t + gridDim.x);   // (the backward stage has no registers to spare earlier)
     if (MODE == MODE_BWD && tid < M) {
         float sacc = 0.0f;
 #pragma unroll
