@@ -189,7 +189,7 @@ __device__ __forceinline__ float upper_half_to_lower(float v)
 {
     const unsigned u = __builtin_bit_cast(unsigned, v);
     auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, pr[1]);
+    return __builtin_bit_cast(float, pr[0]);            // {old upper half, old upper half}: probe_dpp.hip
 }
 // col2im, column direction, for one halo row: lane (c, h) holds tap columns j = 4h + (0..3) of pixel
 // column c; returns on lane L (0..37) the sum over j of the value of column L - j.  The upper half's

@@ -7,7 +7,7 @@ __global__ void k(float *o1, float *o2)
     o1[threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v + 100.0f), 0x138, 0xf, 0xf, true));
     const unsigned u = __builtin_bit_cast(unsigned, v);
     auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    o2[threadIdx.x] = __builtin_bit_cast(float, pr[1]);
+    o2[threadIdx.x] = __builtin_bit_cast(float, pr[0]);
 }
 int main()
 {
