@@ -188,8 +188,10 @@ __device__ __forceinline__ float wave_shr1(float v)
 __device__ __forceinline__ float upper_half_to_lower(float v)
 {
     const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, pr[0]);            // {old upper half, old upper half}: probe_dpp.hip
+    // vdst = v, src = 0: lanes 32-63 of vdst swap with lanes 0-31 of src, so the new src is
+    // {v's upper half, 0}.  (Two distinct registers: swapping a register with itself does nothing useful.)
+    auto pr = __builtin_amdgcn_permlane32_swap(u, 0u, false, false);
+    return __builtin_bit_cast(float, pr[1]);
 }
 // col2im, column direction, for one halo row: lane (c, h) holds tap columns j = 4h + (0..3) of pixel
 // column c; returns on lane L (0..37) the sum over j of the value of column L - j.  The upper half's

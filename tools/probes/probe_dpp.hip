@@ -6,8 +6,8 @@ __global__ void k(float *o1, float *o2)
     const float v = (float)threadIdx.x;
     o1[threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v + 100.0f), 0x138, 0xf, 0xf, true));
     const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    o2[threadIdx.x] = __builtin_bit_cast(float, pr[0]);
+    auto pr = __builtin_amdgcn_permlane32_swap(u, 0u, false, false);
+    o2[threadIdx.x] = __builtin_bit_cast(float, pr[1]);
 }
 int main()
 {
@@ -19,9 +19,9 @@ int main()
     int bad = 0;
     for (int i = 0; i < 64; ++i) {
         float e1 = i == 0 ? 0.0f : 100.0f + (i - 1);
-        float e2 = i < 32 ? (float)(i + 32) : -1.0f;
+        float e2 = i < 32 ? (float)(i + 32) : 0.0f;
         if (h1[i] != e1) ++bad;
-        if (i < 32 && h2[i] != e2) ++bad;
+        if (h2[i] != e2) ++bad;
     }
     printf("wave_shr1: lane0=%g lane1=%g lane32=%g lane63=%g | swap[1]: lane0=%g lane31=%g lane32=%g\n",
            h1[0], h1[1], h1[32], h1[63], h2[0], h2[31], h2[32]);
