@@ -188,10 +188,11 @@ __device__ __forceinline__ float wave_shr1(float v)
 __device__ __forceinline__ float upper_half_to_lower(float v)
 {
     const unsigned u = __builtin_bit_cast(unsigned, v);
-    // vdst = v, src = 0: lanes 32-63 of vdst swap with lanes 0-31 of src, so the new src is
-    // {v's upper half, 0}.  (Two distinct registers: swapping a register with itself does nothing useful.)
+    // permlane32_swap(a, b) exchanges a's upper half with b's lower half; measured on gfx950
+    // (tools/probes/probe_dpp.hip): result[1] = {a.lo, b.lo}, result[0] = {a.hi, b.hi}.  With b = 0 the
+    // wanted {v.hi, 0} is result[0].  (a and b must be distinct registers.)
     auto pr = __builtin_amdgcn_permlane32_swap(u, 0u, false, false);
-    return __builtin_bit_cast(float, pr[1]);
+    return __builtin_bit_cast(float, pr[0]);
 }
 // col2im, column direction, for one halo row: lane (c, h) holds tap columns j = 4h + (0..3) of pixel
 // column c; returns on lane L (0..37) the sum over j of the value of column L - j.  The upper half's
