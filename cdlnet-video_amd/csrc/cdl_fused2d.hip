@@ -184,15 +184,16 @@ __device__ __forceinline__ float wave_shr1(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
-// lanes 0..31 receive the value held by lanes 32..63
+// lanes 0..31 receive the value held by lanes 32..63 (lanes 32..63 receive 0).
+// v_permlane32_swap vdst, src exchanges vdst[32..63] with src[0..31]; with src = 0 the new src is
+// {v.hi, 0}.  Inline asm because hipcc (ROCm 7.2) returns the SAME register for both results of
+// __builtin_amdgcn_permlane32_swap (tools/probes/probe_dpp.hip); s_nop 1 = the two wait states the
+// instruction needs after a VALU write of either operand.
 __device__ __forceinline__ float upper_half_to_lower(float v)
 {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    // permlane32_swap(a, b) exchanges a's upper half with b's lower half; measured on gfx950
-    // (tools/probes/probe_dpp.hip): result[1] = {a.lo, b.lo}, result[0] = {a.hi, b.hi}.  With b = 0 the
-    // wanted {v.hi, 0} is result[0].  (a and b must be distinct registers.)
-    auto pr = __builtin_amdgcn_permlane32_swap(u, 0u, false, false);
-    return __builtin_bit_cast(float, pr[0]);
+    float lo = 0.0f;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "+v"(lo));
+    return lo;
 }
 // col2im, column direction, for one halo row: lane (c, h) holds tap columns j = 4h + (0..3) of pixel
 // column c; returns on lane L (0..37) the sum over j of the value of column L - j.  The upper half's

@@ -6,9 +6,11 @@ __global__ void k(float *o1, float *o2, float *o3)
     const float v = (float)threadIdx.x;
     o1[threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v + 100.0f), 0x138, 0xf, 0xf, true));
     const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto pr = __builtin_amdgcn_permlane32_swap(u, 0u, false, false);
-    o2[threadIdx.x] = __builtin_bit_cast(float, pr[0]);
-    o3[threadIdx.x] = __builtin_bit_cast(float, pr[1]);
+    (void)u;
+    float a = v, b = 0.0f;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    o2[threadIdx.x] = b;       // expected {a.hi, 0}
+    o3[threadIdx.x] = a;       // expected {a.lo, 0}
 }
 int main()
 {
@@ -25,7 +27,7 @@ int main()
         if (h1[i] != e1) ++bad;
         if (h2[i] != e2) ++bad;
     }
-    printf("swap(u,0)[0]: lane0=%g lane31=%g lane32=%g lane63=%g | [1]: lane0=%g lane31=%g lane32=%g lane63=%g\n",
+    printf("asm swap(a=lane,b=0): new b: lane0=%g lane31=%g lane32=%g lane63=%g | new a: lane0=%g lane31=%g lane32=%g lane63=%g\n",
            h2[0], h2[31], h2[32], h2[63], h3[0], h3[31], h3[32], h3[63]);
     printf("wave_shr1: lane0=%g lane1=%g lane32=%g lane63=%g | swap[1]: lane0=%g lane31=%g lane32=%g\n",
            h1[0], h1[1], h1[32], h1[63], h2[0], h2[31], h2[32]);
