@@ -133,6 +133,26 @@ def kernel_probe(cva, net, batch, size, reps=5):
     return rows, dom
 
 
+def pmc_traffic(kernel_label, batch, size, M, P):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile
+    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+    doubled per the gfx950 correction and calibrated on a plain copy).  None when no profile matches
+    this shape (counters cannot be read from inside the timed process)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        sh = prof.get("shape", {})
+        if (sh.get("N"), sh.get("M"), sh.get("H"), sh.get("W"), sh.get("P")) != (batch, M, size, size, P):
+            continue
+        for name, row in prof.get("kernels", {}).items():
+            if kernel_label.startswith(name.split(",")[0]) and name.split(",")[1].rstrip(">") in kernel_label:
+                return row["traffic"], os.path.basename(path)
+    return None, None
+
+
 def cpu_baseline(sd, x, y, sigma, K, P, reps=2):
     """The CPU oracle (PyTorch restatement of the reference, kind='port') timed on this host's cores
     on a bounded sample of the same workload: fwd+bwd of `x.shape[0]` images."""
@@ -226,6 +246,7 @@ def main():
         rows, dom = kernel_probe(cva, net, B, S)
         d = rows[dom]
         note("kernel probe done")
+        traffic, traffic_src = pmc_traffic(dom, B, S, M, P)
         out = {
             "metric": f"Mpix/s denoised (fwd+bwd) at K={K},M={M},P={P}",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -240,7 +261,7 @@ def main():
             "loss": float(loss),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(d["GBps"], 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 5),
-                         "traffic": None, "avg_ms": round(d["ms"], 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_ms": round(d["ms"], 4),
                          "algorithmic_bytes_per_launch": d["bytes"]},
             "kernels": {k: {"ms": round(v["ms"], 4), "per_step": v["per_step"],
                             "GBps": round(v["GBps"], 1)} for k, v in rows.items()},
