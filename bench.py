@@ -148,7 +148,7 @@ def pmc_traffic(kernel_label, batch, size, M, P):
         if (sh.get("N"), sh.get("M"), sh.get("H"), sh.get("W"), sh.get("P")) != (batch, M, size, size, P):
             continue
         for name, row in prof.get("kernels", {}).items():
-            if kernel_label.startswith(name.split(",")[0]) and name.split(",")[1].rstrip(">") in kernel_label:
+            if kernel_label.startswith(name):           # e.g. "k_stage<BWD,split3>" prefixes the probe label
                 return row["traffic"], os.path.basename(path)
     return None, None
 
