@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Throughput + parity of every BASELINE.json configuration on one MI355X (secondary to bench.py,
+which measures the headline configs[1]).  One JSON line per configuration:
+
+    python tools/bench_configs.py [cfg1 cfg3 ...] > gpurun_out/configs.jsonl
+
+For each config: forward-only and forward+backward (loss.backward(), no optimiser) Mpix/s through the
+product modules, the CPU oracle on a bounded sample of the same workload (same box, host threads), the
+max relative error of xhat against the oracle on that sample and both PSNRs.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                                    # noqa: E402
+import cdlnet_video_amd as cva                  # noqa: E402
+from oracle import cdl_oracle as O              # noqa: E402
+
+sys.path.insert(0, ROOT)
+from bench import host_cores                    # noqa: E402
+
+CONFIGS = {
+    # name: (kind, ctor kwargs, input shape, sigma, masked, cpu sample size)
+    "cfg1": ("2d", dict(K=10, M=32, P=5, s=1, C=1), (1, 1, 128, 128), 25.0, False, 1),
+    "cfg1-b10": ("2d", dict(K=10, M=32, P=5, s=1, C=1), (10, 1, 128, 128), 25.0, False, 2),
+    "cfg2": ("2d", dict(K=30, M=64, P=7, s=1, C=1), (64, 1, 256, 256), 25.0, False, 1),
+    "s2030-arch": ("2d", dict(K=30, M=169, P=7, s=2, C=1), (64, 1, 256, 256), 25.0, False, 1),
+    "cfg3": ("3d", dict(K=20, M=48, P=[5, 5, 5], s=1, C=1), (8, 1, 8, 128, 128), 25.0, False, 1),
+    "cfg4": ("2d", dict(K=42, M=64, P=7, s=1, C=3), (8, 3, 256, 256), (1.0, 20.0), True, 1),
+    "cfg5": ("gabor", dict(K=30, M=64, P=7, s=1, C=1, order=1, shared=""), (16, 1, 256, 256), 25.0, False, 1),
+}
+
+
+def ev(fn, reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def run(name):
+    kind, kw, shape, sigma, masked, ncpu = CONFIGS[name]
+    torch.manual_seed(1)
+    cls = {"2d": cva.CDLNet, "3d": cva.CDLNetVideo, "gabor": cva.GDLNet}[kind]
+    extra = {"depth": shape[2]} if kind == "3d" else {}
+    net = cls(**kw, t0=5e-3, adaptive=True, init=True, **extra)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    small = (min(shape[0], 4),) + shape[1:]
+    x = cva.utils.synthetic_clip(small, seed=3)
+    x = x.repeat((shape[0] + small[0] - 1) // small[0], *([1] * (len(shape) - 1)))[:shape[0]]
+    gen = torch.Generator().manual_seed(4)
+    y, sig = cva.awgn(x, sigma if isinstance(sigma, (tuple, list)) else float(sigma), gen)
+    mask = cva.gen_bayer_mask(x) if masked else None
+    if masked:
+        y = mask * y
+    yd, xd = y.cuda(), x.cuda()
+    sd_ = sig.cuda() if torch.is_tensor(sig) else sig
+    md = mask.cuda() if masked else 1
+    pix = 1
+    for d in (shape[0],) + tuple(shape[2:]):
+        pix *= d
+
+    def fwd():
+        with torch.no_grad():
+            return net(yd, sd_, mask=md)
+
+    def fwdbwd():
+        for p in net.parameters():
+            p.grad = None
+        xhat, _ = net(yd, sd_, mask=md)
+        torch.mean((xd - xhat) ** 2).backward()
+
+    reps = 3 if pix > 2e6 else 10
+    f_ms, fb_ms = ev(fwd, reps), ev(fwdbwd, reps)
+    xhat = fwd()[0].cpu()
+
+    # CPU oracle on a bounded sample of the same workload
+    torch.set_num_threads(host_cores())
+    xs, ys = x[:ncpu], y[:ncpu]
+    ss = sig[:ncpu] if torch.is_tensor(sig) else sig
+    ms = mask[:ncpu] if masked else None
+    ndim = 3 if kind == "3d" else 2
+    okw = dict(K=kw["K"], P=kw["P"], s=kw["s"], sigma=ss, adaptive=True, mask=ms, ndim=ndim, gabor=kind == "gabor")
+    with torch.no_grad():
+        t0 = time.perf_counter(); xr, _ = O.ista(sd, ys, **okw); cf = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.loss_and_grads(O.gabor_alias(sd, kw["K"], "") if kind == "gabor" else sd, xs, ys, **okw)
+    cfb = time.perf_counter() - t0
+    cpix = pix / shape[0] * ncpu
+    rel = float((xhat[:ncpu] - xr).abs().max() / xr.abs().max())
+    from cdlnet_video_amd import loop, ops
+    out = {"config": name, "model": f"{cls.__name__} {kw}", "input": list(shape),
+           "fused_path": bool(kind == "2d" and kw["C"] == 1 and kw["s"] == 1 and kw["M"] in (32, 64)),
+           "fwd_ms": round(f_ms, 3), "fwd_mpix_s": round(pix / f_ms / 1e3, 3),
+           "fwdbwd_ms": round(fb_ms, 3), "fwdbwd_mpix_s": round(pix / fb_ms / 1e3, 3),
+           "cpu_fwd_mpix_s": round(cpix / cf / 1e6, 4), "cpu_fwdbwd_mpix_s": round(cpix / cfb / 1e6, 4),
+           "cpu_threads": torch.get_num_threads(), "cpu_sample": ncpu,
+           "xhat_rel_err": rel, "psnr_cpu": round(O.psnr(xs, xr), 4), "psnr_gpu": round(O.psnr(xs, xhat[:ncpu]), 4),
+           "psnr_noisy": round(O.psnr(xs, ys if not masked else xr * 0 + ys), 3)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    for cfg in (sys.argv[1:] or list(CONFIGS)):
+        print(f"[{cfg}] ...", file=sys.stderr, flush=True)
+        run(cfg)
