@@ -35,3 +35,11 @@ static inline bool cdl_geom_ok(const cdl_geom *g)
     // the transpose must map Z*s back onto X exactly (output_padding = s-1): 2p + s - P >= 0 .. s-1
     return true;
 }
+
+// register-tiled variants (cdl_generic_tiled.hip): CDL_EUNSUPPORTED means "use the untiled kernel"
+int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                       const float *gate, const float *tau, float *out, void *stream);
+int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                        const float *mask, const float *sub, float *out, void *stream);
+int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
+                    float *dw, void *stream);

@@ -2,6 +2,7 @@
 // LDS-tiled direct correlation on the vector ALUs: the always-available path and the
 // on-device yardstick for the MFMA kernels in cdl_fused2d.hip.  One code path serves
 // CDLNet (D = 1), the Bayer-masked JDD variant (C = 3, mask), CDLNetVideo and GDLNet.
+#include <cstdlib>
 #include "cdl_common.h"
 
 namespace {
@@ -522,6 +523,10 @@ int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha,
     if (!cdl_geom_ok(g) || !x || !w || !out) return CDL_EINVAL;
     if (out == zin) return CDL_EINVAL;
     if (gate && !zin) return CDL_EINVAL;
+    if (!getenv("CDL_NO_TILED")) {
+        const int rc = cdl_tiled_analysis(g, x, w, alpha, zin, gate, tau, out, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     const int tilesX = (Wz + TILE - 1) / TILE, tilesY = (Hz + TILE - 1) / TILE;
     const int PH = (TILE - 1) * g->sh + g->Ph, PW = (TILE - 1) * g->sw + g->Pw;
@@ -542,6 +547,10 @@ int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate, const fl
                   const float *mask, const float *sub, float *out, void *stream)
 {
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
+    if (!getenv("CDL_NO_TILED")) {
+        const int rc = cdl_tiled_synthesis(g, z, gate, w, alpha, mask, sub, out, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
     const int tilesX = (g->W + TILE - 1) / TILE, tilesY = (g->H + TILE - 1) / TILE;
     // upper bound on the code patch a 16x16 output tile (one d) can touch, per axis
     const int PZD = (g->Pd - 1) / g->sd + 2;
@@ -566,6 +575,10 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
 {
     if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
     if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
+    if (!getenv("CDL_NO_TILED")) {
+        const int rc = cdl_tiled_wgrad(g, z, gate, x, alpha, dw, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
     dim3 grid((unsigned)g->M, (unsigned)(g->C * g->Pd * g->Ph));
     k_wgrad<<<grid, 256, 0, S(stream)>>>(*g, z, gate, x, alpha, dw);
     CDL_LAUNCH_CHECK();

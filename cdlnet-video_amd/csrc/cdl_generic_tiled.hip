@@ -1,0 +1,368 @@
+// Register-tiled variants of the shape-generic fp32 kernels for the common filter widths
+// (Pw in {3,5,7,9}, stride in {1,2}; any C for analysis, C in {1,3} for synthesis; 2-D and 3-D).
+// Each thread owns 4 consecutive output columns, so one LDS row window of 3*s + Pw values feeds
+// 4*Pw FMAs per channel and the filter row arrives as one wave-uniform (scalar) vector load.
+// cdl_analysis / cdl_synthesis (cdl_generic.hip) try these first and fall back to the untiled
+// kernels for every other shape.
+#include "cdl_common.h"
+
+namespace {
+
+constexpr int TX = 64, TY = 16;   // output tile (columns x rows) of a 256-thread workgroup
+constexpr int PXT = 4;            // columns per thread
+constexpr int MCH = 8;            // code channels per register pass
+
+// ------------------------------------------------------------------------------------------
+template <int PW, int SW>
+__global__ __launch_bounds__(256) void k_analysis_t(cdl_geom g, const float *__restrict__ x,
+                                                    const float *__restrict__ w, float alpha,
+                                                    const float *__restrict__ zin,
+                                                    const float *__restrict__ gate,
+                                                    const float *__restrict__ tau,
+                                                    float *__restrict__ out, int tilesX, int tilesY,
+                                                    int PH, int PWp)
+{
+    extern __shared__ float patch[];                       // [C][Pd][PH][PWp]
+    constexpr int WL = (PXT - 1) * SW + PW;                // row window per thread
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b;
+    const int n = blockIdx.y;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int zy = ty * TY + ly, zx0 = tx * TX + lx * PXT;
+    const int y0 = ty * TY * g.sh - g.ph, x0 = tx * TX * SW - g.pw, d0 = zd * g.sd - g.pd;
+
+    const int plane = PH * PWp, pvol = g.C * g.Pd * plane;
+    for (int i = threadIdx.x; i < pvol; i += 256) {
+        const int px = i % PWp;
+        int r = i / PWp;
+        const int py = r % PH; r /= PH;
+        const int kd = r % g.Pd, c = r / g.Pd;
+        const int d = d0 + kd, yy = y0 + py, xx = x0 + px;
+        float v = 0.0f;
+        if (d >= 0 && d < g.D && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+            v = x[((((size_t)n * g.C + c) * g.D + d) * g.H + yy) * g.W + xx];
+        patch[i] = v;
+    }
+    __syncthreads();
+
+    const int taps = g.Pd * g.Ph * PW, wrow = g.C * taps;
+    const float *pbase = patch + (ly * g.sh) * PWp + lx * PXT * SW;
+    for (int m0 = 0; m0 < g.M; m0 += MCH) {
+        float acc[MCH][PXT];
+#pragma unroll
+        for (int j = 0; j < MCH; ++j)
+#pragma unroll
+            for (int p = 0; p < PXT; ++p) acc[j][p] = 0.0f;
+        for (int c = 0; c < g.C; ++c)
+            for (int kd = 0; kd < g.Pd; ++kd)
+                for (int ki = 0; ki < g.Ph; ++ki) {
+                    const float *prow = pbase + ((c * g.Pd + kd) * PH + ki) * PWp;
+                    float win[WL];
+#pragma unroll
+                    for (int i = 0; i < WL; ++i) win[i] = prow[i];
+                    const int wofs = c * taps + (kd * g.Ph + ki) * PW;
+#pragma unroll
+                    for (int j = 0; j < MCH; ++j) {
+                        const float *wr = w + (size_t)min(m0 + j, g.M - 1) * wrow + wofs;   // wave-uniform
+#pragma unroll
+                        for (int kj = 0; kj < PW; ++kj) {
+                            const float wv = wr[kj];
+#pragma unroll
+                            for (int p = 0; p < PXT; ++p) acc[j][p] = fmaf(win[p * SW + kj], wv, acc[j][p]);
+                        }
+                    }
+                }
+        if (zy < Hz) {
+#pragma unroll
+            for (int j = 0; j < MCH; ++j) {
+                const int m = m0 + j;
+                if (m >= g.M) continue;
+                const float t = tau ? tau[n * g.M + m] : 0.0f;
+                const size_t rowi = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz;
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) {
+                    const int zx = zx0 + p;
+                    if (zx >= Wz) continue;
+                    float base = 0.0f;
+                    if (zin) {
+                        base = zin[rowi + zx];
+                        if (gate && gate[rowi + zx] == 0.0f) base = 0.0f;
+                    }
+                    const float u = fmaf(alpha, acc[j][p], base);
+                    out[rowi + zx] = tau ? cdl_shrink(u, t) : u;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthesis: thread owns out[c0..c0+CC)[d][y][x0..x0+3]; code channels pass through LDS MCH at a
+// time and one code depth slice at a time; rows of one wave share the stride phase.
+template <int PW, int SW, int CC>
+__global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__restrict__ z,
+                                                     const float *__restrict__ gate,
+                                                     const float *__restrict__ w, float alpha,
+                                                     const float *__restrict__ mask,
+                                                     const float *__restrict__ sub,
+                                                     float *__restrict__ out, int tilesX, int tilesY,
+                                                     int PZH, int PZW)
+{
+    extern __shared__ float patch[];                       // [MCH][PZH][PZW]
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int d = b;
+    const int n = blockIdx.y;
+    const int lx = threadIdx.x & 15, lw = threadIdx.x >> 6, lr = (threadIdx.x >> 4) & 3;
+    const int ly = lw + 4 * lr;                            // rows of a wave are congruent mod 4
+    const int y = ty * TY + ly, x0 = tx * TX + lx * PXT;
+    const int pw = g.pw;
+    // code-patch origin of this tile (floor division, may be negative: zero filled)
+    const int zy_lo = cdl_floordiv(ty * TY + g.ph - (g.Ph - 1), g.sh);
+    const int zx_lo = cdl_floordiv(tx * TX + pw - (PW - 1), SW);
+    const int plane = PZH * PZW;
+    const int taps = g.Pd * g.Ph * PW;
+    // Row window of one thread.  With B0 = x0 + pw - (PW-1) (numerator of p = 0, kj = PW-1) the tap
+    // (p, kj) has numerator B0 + t, t = p + PW-1 - kj, and is live when SW divides it; its code column
+    // is zx_first + idx(t).  x0 is a multiple of 4 and pw = PW/2, so B0's parity is a constant of PW.
+    constexpr int B0ODD = (SW == 2) ? (((PW - 1) / 2) & 1) : 0;
+    constexpr int WLS = (PXT - 1 + PW - 1 + B0ODD) / SW + 1;
+    float acc[CC][PXT];
+    for (int c0 = 0; c0 < g.C; c0 += CC) {
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int p = 0; p < PXT; ++p) acc[cc][p] = 0.0f;
+        for (int m0 = 0; m0 < g.M; m0 += MCH) {
+            for (int kd = 0; kd < g.Pd; ++kd) {
+                const int td = d + g.pd - kd;
+                if (td < 0 || td % g.sd) continue;          // uniform
+                const int zd = td / g.sd;
+                if (zd >= Dz) continue;
+                __syncthreads();
+                for (int i = threadIdx.x; i < MCH * plane; i += 256) {
+                    const int px = i % PZW;
+                    int r = i / PZW;
+                    const int py = r % PZH, mm = r / PZH;
+                    const int m = m0 + mm, zy = zy_lo + py, zx = zx_lo + px;
+                    float v = 0.0f;
+                    if (m < g.M && zy >= 0 && zy < Hz && zx >= 0 && zx < Wz) {
+                        const size_t idx = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx;
+                        v = z[idx];
+                        if (gate && gate[idx] == 0.0f) v = 0.0f;
+                    }
+                    patch[i] = v;
+                }
+                __syncthreads();
+                const int mlim = min(MCH, g.M - m0);
+                for (int ki = 0; ki < g.Ph; ++ki) {
+                    const int tyy = y + g.ph - ki + g.sh * g.Ph;      // shifted positive
+                    if (tyy % g.sh) continue;                          // same for every row of the wave
+                    const int zyl = tyy / g.sh - g.Ph - zy_lo;
+                    // first code column of the window, relative to the patch
+                    const int zx_first = cdl_floordiv(x0 + pw - (PW - 1), SW) - zx_lo;
+                    const int wbase = (kd * g.Ph + ki) * PW;
+                    for (int mm = 0; mm < mlim; ++mm) {
+                        const float *prow = patch + mm * plane + zyl * PZW + zx_first;
+                        float win[WLS];
+#pragma unroll
+                        for (int i = 0; i < WLS; ++i) win[i] = prow[i];
+#pragma unroll
+                        for (int cc = 0; cc < CC; ++cc) {
+                            if (c0 + cc >= g.C) continue;
+                            const float *wr = w + ((size_t)(m0 + mm) * g.C + c0 + cc) * taps + wbase;   // uniform
+#pragma unroll
+                            for (int kj = 0; kj < PW; ++kj) {
+                                const float wv = wr[kj];
+#pragma unroll
+                                for (int p = 0; p < PXT; ++p) {
+                                    constexpr int dummy = 0; (void)dummy;
+                                    const int t = p + PW - 1 - kj;                  // compile-time after unrolling
+                                    if (SW == 1 || ((t & 1) == B0ODD))
+                                        acc[cc][p] = fmaf(win[SW == 1 ? t : (t + B0ODD) / 2], wv, acc[cc][p]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (y < g.H) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                const int c = c0 + cc;
+                if (c >= g.C) continue;
+                const size_t rowi = ((((size_t)n * g.C + c) * g.D + d) * g.H + y) * g.W;
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) {
+                    const int xo = x0 + p;
+                    if (xo >= g.W) continue;
+                    float v = alpha * acc[cc][p];
+                    if (mask) v *= mask[rowi + xo];
+                    if (sub) v -= sub[rowi + xo];
+                    out[rowi + xo] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient: one workgroup per (m, c, kd, ki) filter row as in the untiled kernel, but every
+// thread takes 4 consecutive code columns per step (one row window of the image feeds 4*PW FMAs)
+// and all-zero quads of the sparse / gated code are skipped.  Fixed reduction order.
+template <int PW, int SW>
+__global__ __launch_bounds__(256) void k_wgrad_t(cdl_geom g, const float *__restrict__ z,
+                                                 const float *__restrict__ gate,
+                                                 const float *__restrict__ x, float alpha,
+                                                 float *__restrict__ dw)
+{
+    __shared__ float red[4][PW];
+    constexpr int WL = (PXT - 1) * SW + PW;
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    const int m = blockIdx.x;
+    int r = blockIdx.y;
+    const int ki = r % g.Ph; r /= g.Ph;
+    const int kd = r % g.Pd;
+    const int c = r / g.Pd;
+    float acc[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) acc[j] = 0.0f;
+
+    const int W4 = (Wz + PXT - 1) / PXT;
+    const int rows = g.N * Dz * Hz;
+    const long items = (long)rows * W4;
+    for (long it = threadIdx.x; it < items; it += 256) {
+        const int row = (int)(it / W4), zx0 = (int)(it % W4) * PXT;
+        const int zy = row % Hz, t = row / Hz;
+        const int zd = t % Dz, n = t / Dz;
+        const int d = zd * g.sd - g.pd + kd, y = zy * g.sh - g.ph + ki;
+        if (d < 0 || d >= g.D || y < 0 || y >= g.H) continue;
+        const size_t zoff = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx0;
+        float zv[PXT];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < PXT; ++p) {
+            float v = (zx0 + p < Wz) ? z[zoff + p] : 0.0f;
+            if (gate && v != 0.0f && gate[zoff + p] == 0.0f) v = 0.0f;
+            zv[p] = v;
+            any |= v != 0.0f;
+        }
+        if (!any) continue;
+        const float *xr = x + ((((size_t)n * g.C + c) * g.D + d) * g.H + y) * g.W;
+        const int xb = zx0 * SW - g.pw;
+        float win[WL];
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            const int xx = xb + i;
+            win[i] = (xx >= 0 && xx < g.W) ? xr[xx] : 0.0f;
+        }
+#pragma unroll
+        for (int kj = 0; kj < PW; ++kj)
+#pragma unroll
+            for (int p = 0; p < PXT; ++p) acc[kj] = fmaf(zv[p], win[p * SW + kj], acc[kj]);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int kj = 0; kj < PW; ++kj) {
+        float v = acc[kj];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wv][kj] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PW) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        dw[((((size_t)m * g.C + c) * g.Pd + kd) * g.Ph + ki) * PW + threadIdx.x] = alpha * v;
+    }
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <int PW, int SW>
+int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                    const float *gate, const float *tau, float *out, void *stream)
+{
+    const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    const int tilesX = (Wz + TX - 1) / TX, tilesY = (Hz + TY - 1) / TY;
+    const int PH = (TY - 1) * g->sh + g->Ph;
+    const int PWp = (((TX - 1) * SW + PW) + 3) & ~3;
+    const size_t lds = (size_t)g->C * g->Pd * PH * PWp * sizeof(float);
+    if (lds > 96 * 1024) return CDL_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_analysis_t<PW, SW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+    }
+    dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N);
+    k_analysis_t<PW, SW><<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, PH, PWp);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int PW, int SW, int CC>
+int launch_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                     const float *mask, const float *sub, float *out, void *stream)
+{
+    const int tilesX = (g->W + TX - 1) / TX, tilesY = (g->H + TY - 1) / TY;
+    const int PZH = (TY - 1 + g->Ph - 1) / g->sh + 2;
+    const int PZW = (TX - 1 + PW - 1) / SW + 2 + 4;          // + slack for the fixed-length row windows
+    const size_t lds = (size_t)MCH * PZH * PZW * sizeof(float);
+    if (lds > 64 * 1024) return CDL_EUNSUPPORTED;
+    dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N);
+    k_synthesis_t<PW, SW, CC><<<grid, 256, lds, S(stream)>>>(*g, z, gate, w, alpha, mask, sub, out, tilesX,
+                                                          tilesY, PZH, PZW);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// Returns CDL_EUNSUPPORTED when the shape has no tiled instantiation (the caller falls back).
+int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                       const float *gate, const float *tau, float *out, void *stream)
+{
+    if (g->sw != g->sh) return CDL_EUNSUPPORTED;
+#define CDL_A(PW_, SW_) if (g->Pw == PW_ && g->sw == SW_) return launch_analysis<PW_, SW_>(g, x, w, alpha, zin, gate, tau, out, stream)
+    CDL_A(3, 1); CDL_A(5, 1); CDL_A(7, 1); CDL_A(9, 1);
+    CDL_A(3, 2); CDL_A(5, 2); CDL_A(7, 2); CDL_A(9, 2);
+#undef CDL_A
+    return CDL_EUNSUPPORTED;
+}
+
+int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                        const float *mask, const float *sub, float *out, void *stream)
+{
+    if (g->sw != g->sh || g->pw != g->Pw / 2) return CDL_EUNSUPPORTED;
+    if (g->C != 1 && g->C != 3) return CDL_EUNSUPPORTED;
+#define CDL_S(PW_, SW_)                                                                              \
+    if (g->Pw == PW_ && g->sw == SW_)                                                                \
+        return g->C == 1 ? launch_synthesis<PW_, SW_, 1>(g, z, gate, w, alpha, mask, sub, out, stream) \
+                         : launch_synthesis<PW_, SW_, 3>(g, z, gate, w, alpha, mask, sub, out, stream)
+    CDL_S(3, 1); CDL_S(5, 1); CDL_S(7, 1); CDL_S(9, 1);
+    CDL_S(3, 2); CDL_S(5, 2); CDL_S(7, 2); CDL_S(9, 2);
+#undef CDL_S
+    return CDL_EUNSUPPORTED;
+}
+
+int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
+                    float *dw, void *stream)
+{
+    if (g->sw != g->sh) return CDL_EUNSUPPORTED;
+    dim3 grid((unsigned)g->M, (unsigned)(g->C * g->Pd * g->Ph));
+#define CDL_W(PW_, SW_)                                                                     \
+    if (g->Pw == PW_ && g->sw == SW_) {                                                     \
+        k_wgrad_t<PW_, SW_><<<grid, 256, 0, S(stream)>>>(*g, z, gate, x, alpha, dw);        \
+        CDL_LAUNCH_CHECK();                                                                 \
+        return 0;                                                                           \
+    }
+    CDL_W(3, 1) CDL_W(5, 1) CDL_W(7, 1) CDL_W(9, 1)
+    CDL_W(3, 2) CDL_W(5, 2) CDL_W(7, 2) CDL_W(9, 2)
+#undef CDL_W
+    return CDL_EUNSUPPORTED;
+}
