@@ -43,7 +43,7 @@ SIGNATURES = {
     "cdl_shrink": [_P, _P, _P, _I, ctypes.c_size_t, _P],
     "cdl_analysis": [_G, _P, _P, _F, _P, _P, _P, _P, _P],
     "cdl_synthesis": [_G, _P, _P, _P, _F, _P, _P, _P, _P],
-    "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P],
+    "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_project_filters": [_P, _I, _I, _P],
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -57,7 +57,8 @@ SIGNATURES = {
     "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
 }
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
-                "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G]}
+                "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
+                "cdl_wgrad_workspace_floats": [_G]}
 
 _lib = None
 

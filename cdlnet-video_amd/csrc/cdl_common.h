@@ -42,4 +42,4 @@ int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float 
 int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                         const float *mask, const float *sub, float *out, void *stream);
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
-                    float *dw, void *stream);
+                    float *dw, float *workspace, size_t workspace_floats, void *stream);

@@ -570,13 +570,21 @@ int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate, const fl
     return 0;
 }
 
+size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
+{
+    if (!cdl_geom_ok(g)) return 0;
+    const size_t total = (size_t)g->M * g->C * g->Pd * g->Ph * g->Pw;
+    size_t chunks = 2048 / ((size_t)g->M * g->C * g->Pd);
+    return total * (chunks < 1 ? 1 : chunks);
+}
+
 int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
-              float *dw, void *stream)
+              float *dw, float *workspace, size_t workspace_floats, void *stream)
 {
     if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
     if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
     if (!getenv("CDL_NO_TILED")) {
-        const int rc = cdl_tiled_wgrad(g, z, gate, x, alpha, dw, stream);
+        const int rc = cdl_tiled_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }
     dim3 grid((unsigned)g->M, (unsigned)(g->C * g->Pd * g->Ph));

@@ -282,6 +282,94 @@ __global__ __launch_bounds__(256) void k_wgrad_t(cdl_geom g, const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// filter gradient, second tier: one workgroup per (m, c, kd) and per chunk of code rows, all
+// PH x PW taps of the filter plane in registers, so the code is read C*Pd times in total instead
+// of C*Pd*Ph times.  Partial sums per row chunk go to `part`; k_wgrad_fold adds them in order.
+template <int PH, int PW, int SW>
+__global__ __launch_bounds__(256) void k_wgrad_p(cdl_geom g, const float *__restrict__ z,
+                                                 const float *__restrict__ gate,
+                                                 const float *__restrict__ x, float *__restrict__ part,
+                                                 int rows_per_chunk)
+{
+    __shared__ float red[4][PH * PW];
+    constexpr int WL = (PXT - 1) * SW + PW;
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    const int m = blockIdx.x;
+    const int kd = blockIdx.y % g.Pd, c = blockIdx.y / g.Pd;
+    float acc[PH][PW];
+#pragma unroll
+    for (int i = 0; i < PH; ++i)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) acc[i][j] = 0.0f;
+
+    const int W4 = (Wz + PXT - 1) / PXT;
+    const int rows = g.N * Dz * Hz;
+    const int r0 = blockIdx.z * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    const long items = (long)(r1 - r0) * W4;
+    for (long it = threadIdx.x; it < items; it += 256) {
+        const int row = r0 + (int)(it / W4), zx0 = (int)(it % W4) * PXT;
+        const int zy = row % Hz, t = row / Hz;
+        const int zd = t % Dz, n = t / Dz;
+        const int d = zd * g.sd - g.pd + kd;
+        if (d < 0 || d >= g.D) continue;
+        const size_t zoff = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx0;
+        float zv[PXT];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < PXT; ++p) {
+            float v = (zx0 + p < Wz) ? z[zoff + p] : 0.0f;
+            if (gate && v != 0.0f && gate[zoff + p] == 0.0f) v = 0.0f;
+            zv[p] = v;
+            any |= v != 0.0f;
+        }
+        if (!any) continue;
+        const float *xplane = x + (((size_t)n * g.C + c) * g.D + d) * g.H * g.W;
+        const int xb = zx0 * SW - g.pw, yb = zy * g.sh - g.ph;
+#pragma unroll
+        for (int ki = 0; ki < PH; ++ki) {
+            const int y = yb + ki;
+            if (y < 0 || y >= g.H) continue;
+            const float *xr = xplane + (size_t)y * g.W;
+            float win[WL];
+#pragma unroll
+            for (int i = 0; i < WL; ++i) {
+                const int xx = xb + i;
+                win[i] = (xx >= 0 && xx < g.W) ? xr[xx] : 0.0f;
+            }
+#pragma unroll
+            for (int kj = 0; kj < PW; ++kj)
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[p], win[p * SW + kj], acc[ki][kj]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < PH; ++i)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            float v = acc[i][j];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wv][i * PW + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < PH * PW) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        // part[chunk][m][c][kd][PH*PW]
+        part[(((size_t)blockIdx.z * g.M + m) * g.C * g.Pd + blockIdx.y) * (PH * PW) + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_wgrad_fold(const float *__restrict__ part, float *__restrict__ dw, float alpha, int chunks,
+                             int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * total + i];
+    dw[i] = alpha * s;
+}
+
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <int PW, int SW>
@@ -351,9 +439,34 @@ int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, co
 }
 
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
-                    float *dw, void *stream)
+                    float *dw, float *workspace, size_t workspace_floats, void *stream)
 {
     if (g->sw != g->sh) return CDL_EUNSUPPORTED;
+    if (workspace) {
+        // second tier: whole filter planes in registers, code rows split into chunks
+        const int total = g->M * g->C * g->Pd * g->Ph * g->Pw;
+        const int rows = g->N * (g->D / g->sd) * (g->H / g->sh);
+        int chunks = 2048 / (g->M * g->C * g->Pd);
+        if (chunks < 1) chunks = 1;
+        if (chunks > rows) chunks = rows;
+        while (chunks > 1 && (size_t)chunks * total > workspace_floats) --chunks;
+        const int rpc = (rows + chunks - 1) / chunks;
+        chunks = (rows + rpc - 1) / rpc;
+        if ((size_t)chunks * total <= workspace_floats) {
+            dim3 grid2((unsigned)g->M, (unsigned)(g->C * g->Pd), (unsigned)chunks);
+#define CDL_P(PH_, PW_, SW_)                                                                              \
+            if (g->Ph == PH_ && g->Pw == PW_ && g->sw == SW_) {                                            \
+                k_wgrad_p<PH_, PW_, SW_><<<grid2, 256, 0, S(stream)>>>(*g, z, gate, x, workspace, rpc);    \
+                CDL_LAUNCH_CHECK();                                                                        \
+                k_wgrad_fold<<<(total + 255) / 256, 256, 0, S(stream)>>>(workspace, dw, alpha, chunks, total); \
+                CDL_LAUNCH_CHECK();                                                                        \
+                return 0;                                                                                  \
+            }
+            CDL_P(3, 3, 1) CDL_P(5, 5, 1) CDL_P(7, 7, 1) CDL_P(9, 9, 1) CDL_P(3, 5, 1) CDL_P(9, 5, 1)
+            CDL_P(3, 3, 2) CDL_P(5, 5, 2) CDL_P(7, 7, 2) CDL_P(9, 9, 2) CDL_P(3, 5, 2) CDL_P(9, 5, 2)
+#undef CDL_P
+        }
+    }
     dim3 grid((unsigned)g->M, (unsigned)(g->C * g->Pd * g->Ph));
 #define CDL_W(PW_, SW_)                                                                     \
     if (g->Pw == PW_ && g->sw == SW_) {                                                     \

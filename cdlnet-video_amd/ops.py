@@ -214,12 +214,20 @@ def synthesis(g: Geometry, z, w, alpha=1.0, gate=None, mask=None, sub=None, out=
     return out
 
 
+_WGRAD_WS = {}
+
+
 def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):
     z, x, gate = _dev(z, "z"), _dev(x, "x"), _opt(gate, "gate")
     dw = torch.empty(g.filter_shape(), device=z.device, dtype=torch.float32)
     gs = g.c_struct()
+    n = int(_lib.lib().cdl_wgrad_workspace_floats(ctypes.byref(gs)))
+    key = (z.device, n)
+    ws = _WGRAD_WS.get(key)                       # one scratch buffer per (device, size), reused
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(max(n, 1), device=z.device, dtype=torch.float32)
     rc = _lib.lib().cdl_wgrad(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(x), float(alpha), _ptr(dw),
-                              _stream())
+                              _ptr(ws), n, _stream())
     _lib.check(rc, "cdl_wgrad")
     return dw
 

@@ -99,7 +99,10 @@ int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate /*nullabl
  * with zg = gate ? [gate!=0]*z : z.  dA_k: (z=g_{k+1}, gate=z_{k+1}, x=r_k, alpha=-1);
  * dB_k: (z=z_k, x=q_k, alpha=+1).  Deterministic (no atomics).  Pw <= 16. dw is overwritten. */
 int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate /*nullable*/, const float *x,
-              float alpha, float *dw, void *stream);
+              float alpha, float *dw, float *workspace /*nullable*/, size_t workspace_floats, void *stream);
+/* Scratch (floats) that lets cdl_wgrad split the pixel range over more workgroups (two-stage,
+ * fixed-order reduction).  Without a workspace a slower single-stage kernel is used. */
+size_t cdl_wgrad_workspace_floats(const cdl_geom *g);
 
 /* Threshold gradients of one iteration: with du = [zout!=0]*g,
  *   dt0[m] = -sum_{n,pix} sign(zout)*du,   dt1[m] = -sum_n c[n] * sum_pix sign(zout)*du
