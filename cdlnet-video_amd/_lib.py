@@ -55,6 +55,9 @@ SIGNATURES = {
     "cdl_fused2d_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "cdl_fused2d_dtau_reduce": [_G, _P, _P, _P, _P, _P],
     "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
+    "cdl_fused2d_forward": [_G, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "cdl_fused2d_backward": [_G, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                             _P, _P, _I, _P],
 }
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],

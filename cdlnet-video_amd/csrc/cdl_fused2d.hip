@@ -783,32 +783,32 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     }
 }
 
-// dt0[m] = sum_rows partial[row][m]; dt1[m] = sum_rows c[row / per_img] * partial[row][m]; one
-// workgroup, 16 strided partial sums per channel, fixed combination order (deterministic).
-__global__ __launch_bounds__(1024) void k_dtau_reduce(const float *__restrict__ partial,
-                                                      const float *__restrict__ c, float *__restrict__ dt0,
-                                                      float *__restrict__ dt1, int N, int per_img, int M)
+// dt0[m] = sum_rows partial[row][m]; dt1[m] = sum_rows c[row / per_img] * partial[row][m].
+// One workgroup per 4 channels: 64 row-strided partial sums per channel, then a fixed-order tree
+// (deterministic).
+__global__ __launch_bounds__(256) void k_dtau_reduce(const float *__restrict__ partial,
+                                                     const float *__restrict__ c, float *__restrict__ dt0,
+                                                     float *__restrict__ dt1, int N, int per_img, int M)
 {
-    __shared__ float r0[16][64], r1[16][64];
-    const int m = threadIdx.x & 63, part = threadIdx.x >> 6;
+    __shared__ float r0[64][4], r1[64][4];
+    const int mi = threadIdx.x & 3, part = threadIdx.x >> 2;
+    const int m = blockIdx.x * 4 + mi;
     float a0 = 0.0f, a1 = 0.0f;
     const int rows = N * per_img;
     if (m < M)
-        for (int row = part; row < rows; row += 16) {
+        for (int row = part; row < rows; row += 64) {
             const float v = partial[(size_t)row * M + m];
             a0 += v;
             if (c) a1 = fmaf(c[row / per_img], v, a1);
         }
-    r0[part][m] = a0;
-    r1[part][m] = a1;
+    r0[part][mi] = a0;
+    r1[part][mi] = a1;
     __syncthreads();
-    if (part == 0 && m < M) {
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { s0 += r0[q][m]; s1 += r1[q][m]; }
-        dt0[m] = s0;
-        dt1[m] = s1;
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        if (part < stride) { r0[part][mi] += r0[part + stride][mi]; r1[part][mi] += r1[part + stride][mi]; }
+        __syncthreads();
     }
+    if (part == 0 && m < M) { dt0[m] = r0[0][mi]; dt1[m] = r1[0][mi]; }
 }
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -969,7 +969,7 @@ int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const 
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
-    k_dtau_reduce<<<1, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, tiles_x(g) * tiles_y(g), g->M);
+    k_dtau_reduce<<<(g->M + 3) / 4, 256, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, tiles_x(g) * tiles_y(g), g->M);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1015,6 +1015,70 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
     k_assemble<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(
         patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
     CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- whole sweeps: every launch of a forward / reverse pass enqueued from one C call ---------------- */
+int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
+                        const float *const *wA, const float *const *wB, float *const *z, float *const *r,
+                        float *xp, void *frags, float *patches, int precision, void *stream)
+{
+    if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
+    if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
+    const size_t nm = (size_t)g->N * g->M;
+    const float *thin = yp;
+    for (int k = 0; k < K; ++k) {
+        int rc = cdl_fused2d_prep(wA[k], wB[(k + 1) % K], frags, g->M, g->Ph, stream);
+        if (rc) return rc;
+        rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, frags, k ? -1.0f : 1.0f, z[k],
+                                  patches, precision, stream);
+        if (rc) return rc;
+        if (k < K - 1) {
+            rc = cdl_fused2d_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
+            thin = r[k];
+        } else {
+            rc = cdl_fused2d_assemble(g, patches, nullptr, nullptr, 1.0f, xp, stream);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *c,
+                         const float *const *wA, const float *const *wB, const float *const *z,
+                         const float *const *r, const float *g_xp, const float *g_z, float *const *dA,
+                         float *const *dB, float *dt, float *du0, float *du1, float *q, void *frags,
+                         float *patches, float *dtau_partial, float *wgrad_ws, int precision, void *stream)
+{
+    if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
+    if (K < 1 || !yp || !wA || !wB || !z || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
+        !patches || !dtau_partial || !wgrad_ws || (K > 1 && !r))
+        return CDL_EINVAL;
+    const int M = g->M;
+    float *du[2] = {du0, du1};
+    int rc = cdl_fused2d_wgrad(g, z[K - 1], g_xp, 1.0f, dB[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
+                               precision, stream);                       // dB_0 = z_K (x) dL/d(D z_K)
+    if (rc) return rc;
+    const float *thin = g_xp, *base = g_z;
+    for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
+        rc = cdl_fused2d_prep(wB[(k + 1) % K], wA[k], frags, M, g->Ph, stream);
+        if (rc) return rc;
+        float *duk = du[flip];
+        rc = cdl_fused2d_stage_bwd(g, thin, base, z[k], frags, duk, patches, dtau_partial, k >= 1, precision, stream);
+        if (rc) return rc;
+        rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
+        if (rc) return rc;
+        if (k >= 1) {
+            rc = cdl_fused2d_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
+            if (rc) return rc;
+            rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, precision, stream);
+            thin = q;
+        } else {
+            rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws, precision, stream);
+        }
+        if (rc) return rc;
+        base = duk;
+    }
     return 0;
 }
 

@@ -56,7 +56,15 @@ def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
 
 
 def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
-    """One launch per iteration (cdl_fused2d_iter_fwd) + a thin assemble launch."""
+    """The whole sweep from one C call (cdl_fused2d_forward): per iteration one fused launch + a thin
+    assemble, enqueued back to back with no per-launch host work."""
+    keep = keep_codes or keep_resid
+    xp, z, codes, resid = ops.fused_forward(g, yp, mask_p, tau, A, B, keep, PRECISION)
+    return xp, z, codes, (resid if keep_resid else [])
+
+
+def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    """Same sweep driven launch by launch from Python (kept for tests and experiments)."""
     K = len(A)
     frags = [ops.fused_prep(A[k], B[(k + 1) % K]) for k in range(K)]   # last one pairs A_{K-1} with D = B_0
     patches = ops.fused_patches(g, yp.device)
@@ -96,8 +104,14 @@ def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
 
 
 def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
-    """Reverse sweep on the fused kernels: per iteration one stage launch (2 fat reads, 1 fat
-    write), a thin assemble, and one MFMA filter-gradient launch (2 fat reads)."""
+    """Reverse sweep from one C call (cdl_fused2d_backward): per iteration one stage launch (2 fat
+    reads, 1 fat write), a thin assemble, and one MFMA filter-gradient launch (2 fat reads)."""
+    return ops.fused_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
+                              PRECISION)
+
+
+def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+    """Same reverse sweep driven launch by launch from Python (kept for tests and experiments)."""
     prec = PRECISION
     dev = yp.device
     dA, dB = [None] * K, [None] * K

@@ -384,3 +384,63 @@ def fused_wgrad(g: Geometry, workspace, X0=None, T0=None, alpha0=1.0, X1=None, T
                                       _stream())
     _lib.check(rc, "cdl_fused2d_wgrad")
     return outs
+
+
+def _ptr_table(tensors):
+    """Host array of device pointers (kept alive by the caller for the duration of the call)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
+    """Whole forward sweep in one C call.  keep=True: every z_k and r_k gets its own buffer (training);
+    keep=False: two ping-pong buffers each.  Returns (xp, z_K, codes, resid)."""
+    K = len(A)
+    yp, tau = _dev(yp, "yp"), _dev(tau, "tau")
+    mask_p = _opt(mask_p, "mask")
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    dev = yp.device
+    nz = K if keep else min(K, 2)
+    nr = (K - 1) if keep else min(K - 1, 2)
+    zbuf = [torch.empty(g.code_shape(), device=dev, dtype=torch.float32) for _ in range(nz)]
+    rbuf = [torch.empty(g.image_shape(), device=dev, dtype=torch.float32) for _ in range(nr)]
+    z = [zbuf[k % nz] for k in range(K)]
+    r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
+    xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
+    frags = torch.empty(_lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
+    patches = fused_patches(g, dev)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
+                                        _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None, _ptr(xp),
+                                        _ptr(frags), _ptr(patches), PRECISION[precision], _stream())
+    _lib.check(rc, "cdl_fused2d_forward")
+    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else [])
+
+
+def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, precision="split3"):
+    """Whole reverse sweep in one C call; returns (dA list, dB list); dt (K,2,M) is written in place."""
+    K = len(A)
+    dev = yp.device
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    codes = [_dev(t, "z") for t in codes]
+    resid = [_dev(t, "r") for t in resid]
+    g_xp, g_z, c, mask_p = _dev(g_xp, "g_xp"), _opt(g_z, "g_z"), _opt(c, "c"), _opt(mask_p, "mask")
+    dA = [torch.empty_like(w) for w in A]
+    dB = [torch.empty_like(w) for w in B]
+    du0 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
+    du1 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32) if K > 1 else du0
+    q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
+    frags = torch.empty(_lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
+    patches = fused_patches(g, dev)
+    dtp = torch.empty((fused_tiles(g), g.M), device=dev, dtype=torch.float32)
+    ws = fused_wgrad_workspace(g, dev)
+    assert dt.is_contiguous() and dt.numel() == K * 2 * g.M
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_backward(
+        ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(c), _ptr_table(A), _ptr_table(B), _ptr_table(codes),
+        _ptr_table(resid) if resid else None, _ptr(g_xp), _ptr(g_z), _ptr_table(dA), _ptr_table(dB), _ptr(dt),
+        _ptr(du0), _ptr(du1), _ptr(q), _ptr(frags), _ptr(patches), _ptr(dtp), _ptr(ws), PRECISION[precision],
+        _stream())
+    _lib.check(rc, "cdl_fused2d_backward")
+    return dA, dB

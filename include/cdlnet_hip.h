@@ -172,6 +172,24 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
                       const float *X1, const float *T1, float alpha1, float *dw1,
                       float *workspace, int precision, void *stream);
 
+/* ---- whole sweeps in one call (same launches as above, enqueued from C: no per-launch host cost) ----
+ * Pointer tables are HOST arrays of device pointers.  Forward: z[k] receives z_{k+1} (K entries; entries
+ * may alias two ping-pong buffers when nothing is kept for training, as long as z[k] != z[k-1]); r[k]
+ * receives r_{k+1} for k < K-1 (same aliasing rule); xp receives D z_K.  frags: cdl_fused2d_frag_bytes(M).
+ * Backward (net.py forward lines in reverse): z[k] = z_{k+1}, r[k] = r_{k+1} as saved by the forward,
+ * g_xp = dL/d(D z_K), g_z = dL/dz_K or NULL; writes dA[k], dB[k] (filter shapes) and dt (K,2,M);
+ * du0/du1 fat scratch, q thin scratch, dtau_partial (tiles x M), wgrad_ws (workspace_floats). */
+int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
+                        const float *tau /*K,N,M*/, const float *const *wA, const float *const *wB,
+                        float *const *z, float *const *r, float *xp, void *frags, float *patches,
+                        int precision, void *stream);
+int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
+                         const float *c /*N, nullable*/, const float *const *wA, const float *const *wB,
+                         const float *const *z, const float *const *r, const float *g_xp,
+                         const float *g_z /*nullable*/, float *const *dA, float *const *dB, float *dt,
+                         float *du0, float *du1, float *q, void *frags, float *patches,
+                         float *dtau_partial, float *wgrad_ws, int precision, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

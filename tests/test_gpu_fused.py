@@ -299,3 +299,37 @@ def test_bf16_precision_keeps_psnr_to_2dp():
     p_ref, p_got = O.psnr(x, xr), O.psnr(x, xhat.cpu())
     log(f"bf16 mode K30 M64 P7: xhat rel err {err:.2e} PSNR ref={p_ref:.4f} ours={p_got:.4f}")
     assert abs(p_ref - p_got) < 0.02
+
+
+def test_c_sweeps_are_bit_identical_to_stepwise_launches():
+    """cdl_fused2d_forward / _backward enqueue exactly the launches the Python loops do: since every
+    kernel is order-fixed, results must match bit for bit (also checks the ping-pong aliasing)."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    o = cva.ops
+    torch.manual_seed(31)
+    K, M, P, N, H, W = 4, 64, 7, 2, 40, 72
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True).cuda()
+    y = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    yp, mean, pads, _ = o.preprocess(y, 1, None)
+    g = o.Geometry.make(N, 1, M, (H, W), (P, P), (3, 3), 1)
+    c = torch.tensor([0.08, 0.11]).cuda()
+    tau = o.thresholds(net.t.detach(), c, N)
+    A = [m.weight.detach() for m in net.A]
+    B = [m.weight.detach() for m in net.B]
+    xp1, z1, codes1, resid1 = loop._forward_fused(g, yp, None, tau, A, B, True, True)
+    xp2, z2, codes2, resid2 = loop._forward_fused_stepwise(g, yp, None, tau, A, B, True, True)
+    assert torch.equal(xp1, xp2) and torch.equal(z1, z2)
+    assert all(torch.equal(a, b) for a, b in zip(codes1, codes2)) and len(codes1) == K
+    assert all(torch.equal(a, b) for a, b in zip(resid1, resid2)) and len(resid1) == K - 1
+    xp3, z3, codes3, resid3 = loop._forward_fused(g, yp, None, tau, A, B, False, False)     # ping-pong buffers
+    assert torch.equal(xp3, xp1) and torch.equal(z3, z1) and len(codes3) == 1 and resid3 == []
+    g_xp = torch.randn(xp1.shape, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for sweep in (loop._backward_fused, loop._backward_fused_stepwise):
+        dt = torch.zeros(K, 2, M, device="cuda")
+        dA, dB = sweep(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt)
+        outs.append((dA, dB, dt))
+    for k in range(K):
+        assert torch.equal(outs[0][0][k], outs[1][0][k]) and torch.equal(outs[0][1][k], outs[1][1][k])
+    assert torch.equal(outs[0][2], outs[1][2])
