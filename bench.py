@@ -174,13 +174,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL ("nccl" on ROCm).  CDL_DIST_BACKEND=gloo rehearses the multi-rank
+    # code path on a box with fewer GPUs than ranks (ranks then share devices round-robin).
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = (local % ndev) if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        backend = os.environ.get("CDL_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import cdlnet_video_amd as cva
     from cdlnet_video_amd.parallel import GradientBucket, broadcast_parameters
