@@ -148,6 +148,46 @@ __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, int vo
 }
 constexpr int OOB = 0x7fff0000;              // byte offset beyond any descriptor range
 
+// 16-byte fat accesses.  In the MFMA C/D layout a lane owns ONE pixel and 4 consecutive channels per
+// register quad; in memory 4 consecutive PIXELS of one channel are contiguous.  So the 4 lanes of a
+// quad each move 16 B (4 pixels of channel 4h + (lane & 3)) and a 4 x 4 transpose inside the quad
+// (two DPP quad_perm exchange stages, 16 VALU ops) converts between the two: 4x fewer memory
+// instructions, whole 128-B lines per quad.  Needs W % 4 == 0 (template WIDE).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// lane p (= lane & 3) register e  <-  lane e register p
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int p)
+{
+    const bool odd = (p & 1) != 0, hi = (p & 2) != 0;
+    {
+        const float r01 = dpp_quad<0xB1>(odd ? a[0] : a[1]);       // partner lane ^ 1
+        const float r23 = dpp_quad<0xB1>(odd ? a[2] : a[3]);
+        if (odd) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
+    }
+    {
+        const float r02 = dpp_quad<0x4E>(hi ? a[0] : a[2]);        // partner lane ^ 2
+        const float r13 = dpp_quad<0x4E>(hi ? a[1] : a[3]);
+        if (hi) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
+    }
+}
+__device__ __forceinline__ void buf_ld4(float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = __builtin_bit_cast(float, v[e]);
+}
+__device__ __forceinline__ void buf_st4(const float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(unsigned, a[e]);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
 // Sum over the 32 pixel lanes of each half-wave of N per-lane values, leaving total #i on lane
 // (c with c mod N == i): a halving butterfly, N-1 exchanges instead of 5N.  Template recursion keeps
 // every register index static.
@@ -218,7 +258,7 @@ __device__ __forceinline__ float col2im_row(const float (&rv)[4], int h)
 // ------------------------------------------------------------------------------------------
 // MODE_FWD / MODE_FIRST: zout = ST(zin + sgn * A r, tau)              (net.py:85,87)
 // MODE_BWD            : zout = [gate != 0] * (zin + A-like r),  dtau partials   (reverse sweep)
-template <int MT, int PREC, int MODE>
+template <int MT, int PREC, int MODE, bool WIDE>
 __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -343,6 +383,9 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                                                     MODE == MODE_BWD ? img : 0);
     const __amdgpu_buffer_rsrc_t rs_out = fat_rsrc(p.zout + (size_t)n * img, img);
     const int lane_off = (int)((4 * h) * HW + x) * 4;
+    const int p4 = c & 3;                                  // WIDE: channel 4h + p4, pixels 4(c>>2) .. +3
+    const int xq = tx0 + wxi * 32 + (c & ~3);
+    const int lane_off_w = (int)((4 * h + p4) * HW + xq) * 4;
 
 #pragma unroll 1
     for (int b = 0; b < RB; ++b) {
@@ -351,6 +394,8 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         const bool valid = xok && (y < p.H);
         const int voff = valid ? lane_off + y * p.W * 4 : OOB;
         const int voff_st = (p.dbg & 1) ? OOB : voff;
+        const int voff_w = (xq < p.W && y < p.H) ? lane_off_w + y * p.W * 4 : OOB;
+        const int voff_wst = (p.dbg & 1) ? OOB : voff_w;
 
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
@@ -360,6 +405,24 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             for (int R = 0; R < MT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) { zc[R][v] = 0.25f; gc[R][v] = 1.0f; }
+        } else if (MODE != MODE_FIRST && WIDE) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int soff = (32 * R + 8 * q4) * hw4;
+                    float a[4];
+                    buf_ld4(a, rs_in, voff_w, soff);
+                    quad_transpose(a, p4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zc[R][4 * q4 + e] = a[e];
+                    if (MODE == MODE_BWD) {
+                        buf_ld4(a, rs_gate, voff_w, soff);
+                        quad_transpose(a, p4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gc[R][4 * q4 + e] = a[e];
+                    }
+                }
         } else if (MODE != MODE_FIRST) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
@@ -428,9 +491,21 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     const float u = fmaf(p.sgn, acc[R][v], base);
                     zz = (p.dbg & 64) ? u : (valid ? cdl_shrink(u, taur[16 * R + v]) : 0.0f);
                 }
-                buf_st(zz, rs_out, voff_st, chl * hw4);
+                if (!WIDE) buf_st(zz, rs_out, voff_st, chl * hw4);
                 acc[R][v] = zz;
             }
+        if (WIDE) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = acc[R][4 * q4 + e];
+                    quad_transpose(a, p4);
+                    buf_st4(a, rs_out, voff_wst, (32 * R + 8 * q4) * hw4);
+                }
+        }
         if (MODE == MODE_BWD && !p.do_synth) continue;
         if (p.dbg & 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
@@ -587,7 +662,7 @@ struct WgradParams {
     int N, H, W, tilesX, tilesY, numTiles;
 };
 
-template <int MT, int PREC>
+template <int MT, int PREC, bool WIDE>
 __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -651,11 +726,26 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
             const int voff = valid ? (int)((4 * h) * HW + (size_t)y * p.W + x) * 4 : OOB;
             const int hw4 = (int)HW * 4;
             float xv[MT][16];
+            if (WIDE) {
+                const int p4 = c & 3, xq = tx0 + wxi * 32 + (c & ~3);
+                const int voff_w = (xq < p.W && y < p.H) ? (int)((4 * h + p4) * HW + (size_t)y * p.W + xq) * 4 : OOB;
 #pragma unroll
-            for (int R = 0; R < MT; ++R)
+                for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    xv[R][v] = buf_ld(rs, voff, (32 * R + 8 * (v >> 2) + (v & 3)) * hw4);
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float a[4];
+                        buf_ld4(a, rs, voff_w, (32 * R + 8 * q4) * hw4);
+                        quad_transpose(a, p4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xv[R][4 * q4 + e] = a[e];
+                    }
+            } else {
+#pragma unroll
+                for (int R = 0; R < MT; ++R)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        xv[R][v] = buf_ld(rs, voff, (32 * R + 8 * (v >> 2) + (v & 3)) * hw4);
+            }
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -833,17 +923,17 @@ inline int debug_flags()
 inline int tiles_x(const cdl_geom *g) { return (g->W + TW - 1) / TW; }
 inline int tiles_y(const cdl_geom *g) { return (g->H + TH - 1) / TH; }
 
-template <int MT, int PREC, int MODE>
+template <int MT, int PREC, int MODE, bool WIDE>
 int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
 {
     static bool attr_done = false;               // idempotent; a race only repeats the call
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_stage<MT, PREC, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_stage<MT, PREC, MODE, WIDE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STAGE);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    k_stage<MT, PREC, MODE><<<grid, NT, LDS_STAGE, st>>>(p);
+    k_stage<MT, PREC, MODE, WIDE><<<grid, NT, LDS_STAGE, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -851,9 +941,15 @@ int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
 template <int MT, int PREC>
 int launch_stage(const FusedParams &p, int mode, dim3 grid, hipStream_t st)
 {
-    if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD>(p, grid, st);
-    if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST>(p, grid, st);
-    return launch_stage_one<MT, PREC, MODE_BWD>(p, grid, st);
+    const bool wide = (p.W & 3) == 0 && !getenv("CDL_FUSED_NARROW");
+    if (wide) {
+        if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD, true>(p, grid, st);
+        if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST, true>(p, grid, st);
+        return launch_stage_one<MT, PREC, MODE_BWD, true>(p, grid, st);
+    }
+    if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD, false>(p, grid, st);
+    if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST, false>(p, grid, st);
+    return launch_stage_one<MT, PREC, MODE_BWD, false>(p, grid, st);
 }
 
 inline int cu_count()
@@ -886,20 +982,27 @@ int wgrad_grid(const cdl_geom *g)
     return (int)(tiles < 512 ? tiles : 512);
 }
 
-template <int MT, int PREC>
-int launch_wgrad(const WgradParams &p, int G, hipStream_t st)
+template <int MT, int PREC, bool WIDE>
+int launch_wgrad_one(const WgradParams &p, int G, hipStream_t st)
 {
     const size_t lds = (size_t)WG_THIN_BYTES + (size_t)8 * MT * 2 * IMG_ELEMS * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_wgrad2d<MT, PREC>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_wgrad2d<MT, PREC, WIDE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    k_wgrad2d<MT, PREC><<<G, 512, lds, st>>>(p);
+    k_wgrad2d<MT, PREC, WIDE><<<G, 512, lds, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <int MT, int PREC>
+int launch_wgrad(const WgradParams &p, int G, hipStream_t st)
+{
+    if ((p.W & 3) == 0 && !getenv("CDL_FUSED_NARROW")) return launch_wgrad_one<MT, PREC, true>(p, G, st);
+    return launch_wgrad_one<MT, PREC, false>(p, G, st);
 }
 
 }  // namespace

@@ -1,9 +1,10 @@
 #!/bin/bash
-# GPU-box timing experiment: k_stage with parts switched off (CDL_FUSED_DEBUG bits, see cdl_fused2d.hip)
-for d in 0 1 2 16 32 64 31 127; do
-  echo "== CDL_FUSED_DEBUG=$d"
-  CDL_FUSED_DEBUG=$d timeout -k 10 100 python tools/bench_kernels.py 2>/dev/null | grep -E "k_iter_fwd\[split3\]\"|k_stage<BWD>\[split3\]|first" | python -c "
+# GPU-box timing experiment: fused kernels with 16-byte (default) vs 4-byte fat accesses
+for n in 0 1; do
+  echo "== CDL_FUSED_NARROW=$n"
+  if [ $n -eq 1 ]; then export CDL_FUSED_NARROW=1; else unset CDL_FUSED_NARROW; fi
+  timeout -k 10 100 python tools/bench_kernels.py 2>/dev/null | grep -E "k_iter_fwd|k_stage<BWD>|k_wgrad2d|yardstick" | python -c "
 import sys, json
 for l in sys.stdin:
-    r = json.loads(l); print('   %-32s %.3f ms' % (r['kernel'], r['ms']))"
+    r = json.loads(l); print('   %-34s %.3f ms  %.0f GB/s' % (r['kernel'], r['ms'], r.get('GBps', 0)))"
 done
