@@ -176,16 +176,17 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], int p)
 }
 __device__ __forceinline__ void buf_ld4(float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = __builtin_bit_cast(float, v[e]);
+    // (bit_cast the whole vector: __builtin_bit_cast(float, v[e]) on a vector ELEMENT reads element 0
+    //  for every e with hipcc / ROCm 7.2 and lets the optimiser shrink the load to one dword)
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    a[0] = f.x; a[1] = f.y; a[2] = f.z; a[3] = f.w;
 }
 __device__ __forceinline__ void buf_st4(const float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    u32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(unsigned, a[e]);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const f32x4 f = {a[0], a[1], a[2], a[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, soff, 0);
 }
 
 // Sum over the 32 pixel lanes of each half-wave of N per-lane values, leaving total #i on lane
