@@ -159,20 +159,22 @@ __device__ __forceinline__ float dpp_quad(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-// lane p (= lane & 3) register e  <-  lane e register p
+// lane p (= lane & 3) register e  <-  lane e register p.  Pure selects (no control flow): DPP reads
+// must see every lane of the quad active.
 __device__ __forceinline__ void quad_transpose(float (&a)[4], int p)
 {
     const bool odd = (p & 1) != 0, hi = (p & 2) != 0;
-    {
-        const float r01 = dpp_quad<0xB1>(odd ? a[0] : a[1]);       // partner lane ^ 1
-        const float r23 = dpp_quad<0xB1>(odd ? a[2] : a[3]);
-        if (odd) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
-    }
-    {
-        const float r02 = dpp_quad<0x4E>(hi ? a[0] : a[2]);        // partner lane ^ 2
-        const float r13 = dpp_quad<0x4E>(hi ? a[1] : a[3]);
-        if (hi) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
-    }
+    const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    const float r01 = dpp_quad<0xB1>(odd ? a0 : a1);               // partner lane ^ 1
+    const float r23 = dpp_quad<0xB1>(odd ? a2 : a3);
+    const float b0 = odd ? r01 : a0, b1 = odd ? a1 : r01;
+    const float b2 = odd ? r23 : a2, b3 = odd ? a3 : r23;
+    const float r02 = dpp_quad<0x4E>(hi ? b0 : b2);                // partner lane ^ 2
+    const float r13 = dpp_quad<0x4E>(hi ? b1 : b3);
+    a[0] = hi ? r02 : b0;
+    a[1] = hi ? r13 : b1;
+    a[2] = hi ? b2 : r02;
+    a[3] = hi ? b3 : r13;
 }
 __device__ __forceinline__ void buf_ld4(float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             for (int R = 0; R < MT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) { zc[R][v] = 0.25f; gc[R][v] = 1.0f; }
-        } else if (MODE != MODE_FIRST && WIDE) {
+        } else if (MODE != MODE_FIRST && WIDE && !(p.dbg & 128)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -492,10 +494,10 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     const float u = fmaf(p.sgn, acc[R][v], base);
                     zz = (p.dbg & 64) ? u : (valid ? cdl_shrink(u, taur[16 * R + v]) : 0.0f);
                 }
-                if (!WIDE) buf_st(zz, rs_out, voff_st, chl * hw4);
+                if (!WIDE || (p.dbg & 256)) buf_st(zz, rs_out, voff_st, chl * hw4);
                 acc[R][v] = zz;
             }
-        if (WIDE) {
+        if (WIDE && !(p.dbg & 256)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll

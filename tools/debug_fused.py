@@ -38,7 +38,28 @@ def run(N, M, P, H, W, seed):
 
 
 if __name__ == "__main__":
-    run(2, 64, 7, 50, 70, 50 * 70 + 64)
-    run(2, 64, 7, 50, 70, 1)
-    run(1, 64, 7, 50, 70, 2)
-    run(2, 64, 7, 48, 64, 3)
+    import collections
+    o = cva.ops
+    N, M, P, H, W = 1, 64, 7, 128, 128
+    gen = torch.Generator().manual_seed(5)
+    geom = o.Geometry.make(N, 1, M, (H, W), (P, P), (3, 3), 1)
+    r = torch.randn(N, 1, H, W, generator=gen).cuda()
+    z = torch.randn(N, M, H, W, generator=gen).cuda()
+    wA = (torch.randn(M, 1, P, P, generator=gen) * 0.15).cuda()
+    tau = torch.full((N, M), 0.3).cuda()
+    frags = o.fused_prep(wA, wA)
+    patches = o.fused_patches(geom, "cuda")
+    ref = o.analysis(geom, r, wA, -1.0, z, None, tau)
+    got = o.fused_iter(geom, r, z, tau, frags, -1.0, patches, "split3")
+    d = (got - ref).abs()
+    bad = (d > 1e-3).nonzero()
+    print("bad", len(bad), "of", d.numel())
+    if len(bad):
+        ys = collections.Counter((bad[:, 2] // 8).tolist()); xs = collections.Counter((bad[:, 3] // 4).tolist())
+        chs = collections.Counter(bad[:, 1].tolist())
+        print("by row block (y//8):", sorted(ys.items()))
+        print("by x quad (x//4) first 12:", sorted(xs.items())[:12])
+        print("by channel first 12:", sorted(chs.items())[:12])
+        for idx in bad[:6].tolist():
+            n, ch, y, x = idx
+            print(f"  ch={ch} y={y} x={x} got={float(got[n,ch,y,x]):+.4f} ref={float(ref[n,ch,y,x]):+.4f}")
