@@ -154,6 +154,9 @@ constexpr int OOB = 0x7fff0000;              // byte offset beyond any descripto
 // (two DPP quad_perm exchange stages, 16 VALU ops) converts between the two: 4x fewer memory
 // instructions, whole 128-B lines per quad.  Needs W % 4 == 0 (template WIDE).
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#ifndef WIDE_STORE_NOPS
+#define WIDE_STORE_NOPS 16          // wait states after a 16-byte store before its data VGPRs may be rewritten
+#endif
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v)
 {
@@ -189,6 +192,11 @@ __device__ __forceinline__ void buf_st4(const float (&a)[4], __amdgpu_buffer_rsr
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     const f32x4 f = {a[0], a[1], a[2], a[3]};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, soff, 0);
+    if (WIDE_STORE_NOPS) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop %0" ::"n"(WIDE_STORE_NOPS - 1));
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // Sum over the 32 pixel lanes of each half-wave of N per-lane values, leaving total #i on lane

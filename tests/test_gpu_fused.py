@@ -333,3 +333,45 @@ def test_c_sweeps_are_bit_identical_to_stepwise_launches():
     for k in range(K):
         assert torch.equal(outs[0][0][k], outs[1][0][k]) and torch.equal(outs[0][1][k], outs[1][1][k])
     assert torch.equal(outs[0][2], outs[1][2])
+
+
+def test_wide_and_narrow_fat_access_paths_are_bit_identical_at_full_size():
+    """The 16-byte access path (quad transposes + dwordx4 buffer ops) against the 4-byte path on the
+    full cfg2 tensors (64 x 64 x 256 x 256): every kernel is order-fixed, so any difference is a bug
+    (this is the test that exposed the dwordx4 store-data hazard, see cdl_fused2d.hip WIDE_STORE_NOPS)."""
+    import os
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    N, M, P, H, W = 64, 64, 7, 256, 256
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    geom = o.Geometry.make(N, 1, M, (H, W), (P, P), (3, 3), 1)
+    r = torch.randn(N, 1, H, W, device="cuda", generator=gen)
+    z = torch.randn(N, M, H, W, device="cuda", generator=gen)
+    z *= (torch.rand(N, M, H, W, device="cuda", generator=gen) < 0.3)
+    gup = torch.randn(N, M, H, W, device="cuda", generator=gen)
+    w1 = torch.randn(M, 1, P, P, device="cuda", generator=gen) * 0.15
+    w2 = torch.randn(M, 1, P, P, device="cuda", generator=gen) * 0.15
+    tau = torch.rand(N, M, device="cuda", generator=gen) * 0.5 + 0.01
+    frags = o.fused_prep(w1, w2)
+    ws = o.fused_wgrad_workspace(geom, "cuda")
+
+    def run():
+        patches = o.fused_patches(geom, "cuda")
+        dtp = torch.empty(o.fused_tiles(geom), M, device="cuda")
+        zf = o.fused_iter(geom, r, z, tau, frags, -1.0, patches, "split3")
+        pf = patches.clone()
+        du = o.fused_stage_bwd(geom, r, gup, z, frags, patches, dtp, True, "split3")
+        d0, d1 = o.fused_wgrad(geom, ws, gup, r, -1.0, z, r, 1.0, "split3")
+        return zf, pf, du, patches.clone(), dtp, d0, d1
+
+    wide = run()
+    wide2 = run()
+    os.environ["CDL_FUSED_NARROW"] = "1"
+    try:
+        narrow = run()
+    finally:
+        del os.environ["CDL_FUSED_NARROW"]
+    names = ("z'", "fwd patches", "du", "bwd patches", "dtau partials", "dA", "dB")
+    for name, a, b, c in zip(names, wide, narrow, wide2):
+        assert torch.equal(a, b), f"wide vs narrow differ: {name} ({int((a != b).sum())} elements)"
+        assert torch.equal(a, c), f"wide path not reproducible: {name}"
