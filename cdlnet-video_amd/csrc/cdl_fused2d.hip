@@ -152,7 +152,10 @@ constexpr int OOB = 0x7fff0000;              // byte offset beyond any descripto
 // register quad; in memory 4 consecutive PIXELS of one channel are contiguous.  So the 4 lanes of a
 // quad each move 16 B (4 pixels of channel 4h + (lane & 3)) and a 4 x 4 transpose inside the quad
 // (two DPP quad_perm exchange stages, 16 VALU ops) converts between the two: 4x fewer memory
-// instructions, whole 128-B lines per quad.  Needs W % 4 == 0 (template WIDE).
+// instructions.  Needs W % 4 == 0 (template WIDE).  Opt-in: see launch_stage for the measured result.
+// A dwordx4 buffer store must be followed by wait states before its data VGPRs are rewritten: with
+// the two the compiler inserts, lanes 12-15 of every 16-lane row of waves 4-7 stored stale data
+// (found by tests/test_gpu_fused.py::test_wide_and_narrow...); WIDE_STORE_NOPS = 16 is clean.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifndef WIDE_STORE_NOPS
 #define WIDE_STORE_NOPS 16          // wait states after a 16-byte store before its data VGPRs may be rewritten
@@ -952,7 +955,12 @@ int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
 template <int MT, int PREC>
 int launch_stage(const FusedParams &p, int mode, dim3 grid, hipStream_t st)
 {
-    const bool wide = (p.W & 3) == 0 && !getenv("CDL_FUSED_NARROW");
+    // The 16-byte path is opt-in (CDL_FUSED_WIDE=1): measured on MI355X it is SLOWER than 4-byte
+    // accesses (fwd 0.76 vs 0.49 ms, bwd 1.06 vs 0.66 ms at the cfg2 shape) -- a quad's 16-B pieces
+    // sit in 4 different channel rows, so one dwordx4 instruction touches 8 half-lines per 16-lane pass
+    // where the dword form touches 2 whole lines.  Kept (bit-identical, tested) as the access shape a
+    // bf16-storage mode will need.
+    const bool wide = (p.W & 3) == 0 && getenv("CDL_FUSED_WIDE") != nullptr;
     if (wide) {
         if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD, true>(p, grid, st);
         if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST, true>(p, grid, st);
@@ -1012,7 +1020,7 @@ int launch_wgrad_one(const WgradParams &p, int G, hipStream_t st)
 template <int MT, int PREC>
 int launch_wgrad(const WgradParams &p, int G, hipStream_t st)
 {
-    if ((p.W & 3) == 0 && !getenv("CDL_FUSED_NARROW")) return launch_wgrad_one<MT, PREC, true>(p, G, st);
+    if ((p.W & 3) == 0 && getenv("CDL_FUSED_WIDE")) return launch_wgrad_one<MT, PREC, true>(p, G, st);
     return launch_wgrad_one<MT, PREC, false>(p, G, st);
 }
 

@@ -364,13 +364,13 @@ def test_wide_and_narrow_fat_access_paths_are_bit_identical_at_full_size():
         d0, d1 = o.fused_wgrad(geom, ws, gup, r, -1.0, z, r, 1.0, "split3")
         return zf, pf, du, patches.clone(), dtp, d0, d1
 
-    wide = run()
-    wide2 = run()
-    os.environ["CDL_FUSED_NARROW"] = "1"
+    narrow = run()
+    os.environ["CDL_FUSED_WIDE"] = "1"
     try:
-        narrow = run()
+        wide = run()
+        wide2 = run()
     finally:
-        del os.environ["CDL_FUSED_NARROW"]
+        del os.environ["CDL_FUSED_WIDE"]
     names = ("z'", "fwd patches", "du", "bwd patches", "dtau partials", "dA", "dB")
     for name, a, b, c in zip(names, wide, narrow, wide2):
         assert torch.equal(a, b), f"wide vs narrow differ: {name} ({int((a != b).sum())} elements)"
