@@ -45,6 +45,8 @@ SIGNATURES = {
     "cdl_synthesis": [_G, _P, _P, _P, _F, _P, _P, _P, _P],
     "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
+    "cdl_prox_csr": [_G, _P, _P, _P, _P, _P, _P, _P, _P],
+    "cdl_prox_csr_bwd": [_G] + [_P] * 15 + [ctypes.c_size_t, _P],
     "cdl_project_filters": [_P, _I, _I, _P],
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -61,7 +63,7 @@ SIGNATURES = {
 }
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
-                "cdl_wgrad_workspace_floats": [_G]}
+                "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G]}
 
 _lib = None
 

@@ -617,19 +617,15 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
 // ------------------------------------------------------------------------------------------
 // out[n,Y,X] = (mask ? mask : 1) * alpha * sum_{patches covering (Y,X)} patch - (sub ? sub : 0)
-__global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patches,
-                                                  const float *__restrict__ mask,
-                                                  const float *__restrict__ sub, float alpha,
-                                                  float *__restrict__ out, int N, int H, int W,
-                                                  int tilesX, int tilesY)
+// The covering patches are visited in (tile row, tile column) order: a fixed summation order.  A pixel
+// at least HALO away from its tile's border is covered by its own patch only (the common case).
+__device__ __forceinline__ float patch_sum(const float *__restrict__ patches, int n, int Y, int X,
+                                           int tilesX, int tilesY)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)N * H * W;
-    if (i >= total) return;
-    const int X = i % W;
-    const size_t r = i / W;
-    const int Y = r % H, n = r / H;
     const int tyc = Y / TH, txc = X / TW;
+    const int ly = Y - tyc * TH, lx = X - txc * TW;
+    const float *own = patches + (((size_t)n * tilesY + tyc) * tilesX + txc) * SLAB;
+    if (ly >= HALO && ly < TH - HALO && lx >= HALO && lx < TW - HALO) return own[(ly + HALO) * RTW + lx + HALO];
     float sum = 0.0f;
     for (int ty = tyc - 1; ty <= tyc + 1; ++ty) {
         if (ty < 0 || ty >= tilesY) continue;
@@ -642,7 +638,22 @@ __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patc
             sum += patches[(((size_t)n * tilesY + ty) * tilesX + tx) * SLAB + yy * RTW + xx];
         }
     }
-    sum *= alpha;
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patches,
+                                                  const float *__restrict__ mask,
+                                                  const float *__restrict__ sub, float alpha,
+                                                  float *__restrict__ out, int N, int H, int W,
+                                                  int tilesX, int tilesY)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * H * W;
+    if (i >= total) return;
+    const int X = i % W;
+    const size_t r = i / W;
+    const int Y = r % H, n = r / H;
+    float sum = alpha * patch_sum(patches, n, Y, X, tilesX, tilesY);
     if (mask) sum *= mask[i];
     if (sub) sum -= sub[i];
     out[i] = sum;

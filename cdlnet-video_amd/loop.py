@@ -192,6 +192,120 @@ class UnrolledISTA(torch.autograd.Function):
         return (None, None, None, dt.reshape(t.shape), None, *dA, *dB)
 
 
+# ------------------------------------------------------------------------------------------
+# CSR temporal variants (reference model/net.py:426-463, 525-568):
+# the same loop with the shrinkage replaced by prox_CSR / prox_CSR_f2 around a neighbour frame's code.
+#     u_0 = A_0 yp                       z_1     = prox(u_0; zp[, za], lam_0, gam_0)
+#     u_k = z_k - A_k(mask B_k z_k - yp) z_{k+1} = prox(u_k; ...)
+# The reverse sweep needs u_k (the derivative masks of the nested shrinkages are not recoverable from
+# z_{k+1}), so the training forward keeps u_k next to z_k; everything else is _backward_generic with
+# the gating done by cdl_prox_csr_bwd, which also accumulates the neighbour-code gradients.
+def _forward_csr(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep):
+    K = len(A)
+    us, codes, resid = [], [], []
+    g2 = (lambda k: gam2[k]) if za is not None else (lambda k: None)
+    u = ops.analysis(g, yp, A[0], 1.0, None, None, None)
+    z = ops.prox_csr(g, u, zp, lam[0], gam1[0], za, g2(0))
+    for k in range(1, K):
+        if keep:
+            us.append(u)
+            codes.append(z)
+        r = ops.synthesis(g, z, B[k], 1.0, None, mask_p, yp)
+        u = ops.analysis(g, r, A[k], -1.0, z, None, None, out=None if keep else u)    # u, z ping-pong
+        z = ops.prox_csr(g, u, zp, lam[k], gam1[k], za, g2(k), out=None if keep else z)
+        if keep:
+            resid.append(r)
+    if keep:
+        us.append(u)
+        codes.append(z)
+    xp = ops.synthesis(g, z, B[0], 1.0)
+    return xp, z, us, codes, resid
+
+
+class TemporalISTA(torch.autograd.Function):
+    """(y, mask, c, z_prev, z_after|None, t, g1, g2|None, A.., B..) -> (xhat, z_K); gradients for the
+    neighbour codes, the three threshold families and both filter banks."""
+
+    @staticmethod
+    def forward(ctx, y, mask, c, zp, za, t, g1, g2, cfg, *weights):
+        K, s = cfg["K"], cfg["s"]
+        A, B = weights[:K], weights[K:]
+        yp, mean, pads, mask_p = ops.preprocess(y, s, mask)
+        N, C = yp.shape[:2]
+        P = tuple(A[0].shape[2:])
+        nd = yp.dim() - 2
+        g = ops.Geometry.make(N, C, A[0].shape[0], yp.shape[2:], P, tuple(p // 2 for p in P), [s] * nd)
+        if tuple(zp.shape) != g.code_shape() or (za is not None and tuple(za.shape) != g.code_shape()):
+            raise ValueError(f"neighbour code shape {tuple(zp.shape)} does not match this frame's {g.code_shape()}")
+        zp = zp.contiguous()
+        za = za.contiguous() if za is not None else None
+        lam, gam1 = ops.thresholds(t, c, N), ops.thresholds(g1, c, N)
+        gam2 = ops.thresholds(g2, c, N) if za is not None else None
+        ctx.set_materialize_grads(False)
+        keep = any(ctx.needs_input_grad)
+        xp, z, us, codes, resid = _forward_csr(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep)
+        xhat = ops.postprocess(xp, mean, pads)
+        ctx.geom, ctx.pads, ctx.K = g, pads, K
+        ctx.has_mask, ctx.has_c, ctx.has_after = mask_p is not None, c is not None, za is not None
+        if keep:
+            empty = yp.new_empty(0)
+            ctx.save_for_backward(yp, mask_p if mask_p is not None else empty, c if c is not None else empty,
+                                  zp, za if za is not None else empty, t, g1, g2 if za is not None else empty,
+                                  lam, gam1, gam2 if za is not None else empty, *weights, *us, *codes, *resid)
+        return xhat, z
+
+    @staticmethod
+    def backward(ctx, g_xhat, g_z):
+        K, g = ctx.K, ctx.geom
+        sv = ctx.saved_tensors
+        yp, mask_p, c, zp, za, t, g1, g2, lam, gam1, gam2 = sv[:11]
+        mask_p = mask_p if ctx.has_mask else None
+        c = c if ctx.has_c else None
+        za, gam2 = (za, gam2) if ctx.has_after else (None, None)
+        A, B = sv[11:11 + K], sv[11 + K:11 + 2 * K]
+        us = sv[11 + 2 * K:11 + 3 * K]
+        codes = sv[11 + 3 * K:11 + 4 * K]
+        resid = sv[11 + 4 * K:]
+        dev = yp.device
+        dt = torch.zeros((K, 2, g.M), device=dev, dtype=torch.float32)
+        dg1 = torch.zeros_like(dt)
+        dg2 = torch.zeros_like(dt) if za is not None else None
+        need_zp, need_za = ctx.needs_input_grad[3], za is not None and ctx.needs_input_grad[4]
+        gzp = torch.zeros_like(zp) if need_zp else None
+        gza = torch.zeros_like(zp) if need_za else None
+        dA, dB = [None] * K, [None] * K
+        zK = codes[K - 1]
+        if g_xhat is not None:
+            g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads)
+            dB[0] = ops.wgrad(g, zK, g_xp, 1.0)
+            gk = ops.analysis(g, g_xp, B[0], 1.0, g_z.contiguous() if g_z is not None else None, None, None)
+        else:
+            dB[0] = torch.zeros_like(B[0])
+            gk = g_z.contiguous().clone() if g_z is not None else torch.zeros_like(zK)
+
+        def prox_bwd(k, gk):          # gk (dL/dz_{k+1}) -> dL/du_k, in place
+            return ops.prox_csr_bwd(g, gk, us[k], zp, lam[k], gam1[k], c, dt[k], dg1[k], za,
+                                    gam2[k] if za is not None else None, dg2[k] if za is not None else None,
+                                    gzp, gza, out=gk)
+
+        for k in range(K - 1, 0, -1):
+            gu = prox_bwd(k, gk)
+            q = ops.synthesis(g, gu, A[k], -1.0, None, mask_p, None)
+            dA[k] = ops.wgrad(g, gu, resid[k - 1], -1.0)
+            dB[k] = ops.wgrad(g, codes[k - 1], q, 1.0)
+            gk = ops.analysis(g, q, B[k], 1.0, gu, None, None)
+        gu = prox_bwd(0, gk)
+        dA[0] = ops.wgrad(g, gu, yp, 1.0)
+        return (None, None, None, gzp, gza, dt.reshape(t.shape), dg1.reshape(g1.shape),
+                dg2.reshape(g2.shape) if dg2 is not None else None, None, *dA, *dB)
+
+
+def run_csr(y, mask, c, z_prev, z_after, t, g1, g2, A, B, s):
+    """Front end of the neighbour branches; the no-neighbour branch is `run`."""
+    cfg = {"K": len(A), "s": int(s)}
+    return TemporalISTA.apply(y, mask, c, z_prev, z_after, t, g1, g2, cfg, *A, *B)
+
+
 def run(y, mask, c, t, A, B, s, all_codes=False):
     """Convenience front end used by the modules."""
     cfg = {"K": len(A), "s": int(s), "all_codes": bool(all_codes)}

@@ -171,6 +171,133 @@ class CDLNet(_ISTANet):
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
 
+# ------------------------------------------------------------------------------------------ CSR
+def prox_CSR(u, z_prev, lambd, gamma):
+    """The reference's helper (net.py:229-242) on the device; lambd, gamma broadcastable to (N, M, 1, 1)."""
+    return _prox(u, z_prev, None, lambd, gamma, None)
+
+
+def prox_CSR_f2(u, z_prev, z_after, lambd, gamma1, gamma2):
+    """The reference's helper (net.py:244-262) on the device."""
+    return _prox(u, z_prev, z_after, lambd, gamma1, gamma2)
+
+
+def _prox(u, zp, za, lam, g1, g2):
+    N, M = u.shape[:2]
+    sp = tuple(u.shape[2:])
+    g = ops.Geometry.make(N, 1, M, sp, (1,) * len(sp), (0,) * len(sp), 1)
+
+    def rows(t):
+        t = torch.as_tensor(t, dtype=torch.float32, device=u.device)
+        while t.dim() < u.dim():
+            t = t.unsqueeze(0)
+        return torch.broadcast_to(t, (N, M) + (1,) * len(sp)).reshape(N, M).contiguous()
+
+    return ops.prox_csr(g, u, zp, rows(lam), rows(g1), za, rows(g2) if za is not None else None)
+
+
+class _CSRBase(_ISTANet):
+    """Constructor plumbing shared by the two CSR nets (2-D only, like the reference's)."""
+
+    def _banks(self, K, M, P, s, C):
+        A = nn.ModuleList([_Analysis2d(C, M, P, stride=s, padding=(P - 1) // 2, bias=False) for _ in range(K)])
+        B = nn.ModuleList([_Synthesis2d(M, C, P, stride=s, padding=(P - 1) // 2, output_padding=s - 1,
+                                        bias=False) for _ in range(K)])
+        return A, B
+
+    def _spectral_init(self, K, M, P, s, C, init):
+        W = torch.randn(M, C, P, P)
+        for k in range(K):
+            self.A[k].weight.data = W.clone()
+            self.B[k].weight.data = W.clone()
+        if init:
+            print("Running power-method on initial dictionary...")
+            with torch.no_grad():
+                op = gram_operator(self.A[0].weight, self.D.weight, s, (P - 1) // 2)
+                L = power_method(op, torch.rand(1, C, 128, 128), num_iter=200, verbose=False)[0]
+            print(f"Done. L={L:.3e}.")
+            if L < 0:
+                print("STOP: something is very very wrong...")
+                sys.exit()
+            for k in range(K):
+                self.A[k].weight.data /= np.sqrt(L)
+                self.B[k].weight.data /= np.sqrt(L)
+
+    @torch.no_grad()
+    def project(self):
+        """net.py:419-424 / 518-523: only `t`, `A`, `B` are projected (not t2, g*, A2, B2)."""
+        self.t.clamp_(0.0)
+        for k in range(self.K):
+            ops.project_filters_(self.A[k].weight.data)
+            ops.project_filters_(self.B[k].weight.data)
+
+    def _prep(self, y, sigma, mask):
+        if not y.is_cuda:
+            raise RuntimeError(
+                f"{type(self).__name__}.forward: input is on {y.device}. This package has no CPU "
+                "compute path; the iterations run in HIP kernels on a ROCm device.")
+        y = y.to(torch.float32)
+        return y, _mask_tensor(mask, y), _noise_scale(sigma, self.adaptive, y.shape[0], y.device)
+
+
+class CDLNet_CSR(_CSRBase):
+    """CDLNet with the frame-recurrent CSR prior (net.py:363-463): without a neighbour code the plain
+    loop on the second bank (A2, B2, t2; the final synthesis is still D = B[0]); with `z_prev` the
+    first bank and prox_CSR(., z_prev, t, g)."""
+
+    def __init__(self, K=3, M=64, P=7, s=1, C=1, t0=0, adaptive=False, init=True):
+        super().__init__()
+        if P % 2 == 0:
+            raise ValueError("P must be odd (the reference's conv / conv-transpose pair needs it)")
+        self.A, self.B = self._banks(K, M, P, s, C)
+        self.A2, self.B2 = self._banks(K, M, P, s, C)
+        self.D = self.B[0]
+        self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self.t2 = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self.g = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self._spectral_init(K, M, P, s, C, init)
+        self.K, self.M, self.P, self.s, self.t0, self.adaptive = K, M, P, s, t0, adaptive
+
+    def forward(self, y, z_prev=None, sigma=None, mask=1):
+        y, mask_t, c = self._prep(y, sigma, mask)
+        if z_prev is None:
+            A = [m.weight for m in self.A2]
+            B = [self.B[0].weight] + [m.weight for m in self.B2][1:]      # B2[0] is never applied
+            xhat, z = loop.run(y, mask_t, c, self.t2, A, B, self.s)[:2]
+            return xhat, z
+        A, B = self._filters()
+        return loop.run_csr(y, mask_t, c, z_prev, None, self.t, self.g, None, A, B, self.s)
+
+
+class CDLNet_CSRf2(_CSRBase):
+    """CDLNet with previous- and next-frame CSR priors (net.py:464-568): one bank, thresholds t, g1, g2;
+    the branch is chosen by which neighbour codes are given."""
+
+    def __init__(self, K=3, M=64, P=7, s=1, C=1, t0=0, adaptive=False, init=True):
+        super().__init__()
+        if P % 2 == 0:
+            raise ValueError("P must be odd (the reference's conv / conv-transpose pair needs it)")
+        self.A, self.B = self._banks(K, M, P, s, C)
+        self.D = self.B[0]
+        self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self.g1 = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self.g2 = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1))
+        self._spectral_init(K, M, P, s, C, init)
+        self.K, self.M, self.P, self.s, self.t0, self.adaptive = K, M, P, s, t0, adaptive
+
+    def forward(self, y, z_prev=None, z_after=None, sigma=None, mask=1):
+        y, mask_t, c = self._prep(y, sigma, mask)
+        A, B = self._filters()
+        if z_prev is None and z_after is None:
+            xhat, z = loop.run(y, mask_t, c, self.t, A, B, self.s)[:2]
+            return xhat, z
+        if z_prev is not None and z_after is not None:
+            return loop.run_csr(y, mask_t, c, z_prev, z_after, self.t, self.g1, self.g2, A, B, self.s)
+        if z_prev is not None:
+            return loop.run_csr(y, mask_t, c, z_prev, None, self.t, self.g1, None, A, B, self.s)
+        return loop.run_csr(y, mask_t, c, z_after, None, self.t, self.g2, None, A, B, self.s)
+
+
 # ------------------------------------------------------------------------------------------ 3-D
 class CDLNetVideo(_ISTANet):
     """3-D (video / volume) twin; `P` is (kD, kH, kW) or an int (cube)."""

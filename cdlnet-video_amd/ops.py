@@ -245,6 +245,48 @@ def tau_grad(g: Geometry, gup, zout, c, dt_k):
     _lib.check(rc, "cdl_tau_grad")
 
 
+def prox_csr(g: Geometry, u, z_prev, lam, gam1, z_after=None, gam2=None, out=None):
+    """prox_CSR (z_after None) / prox_CSR_f2 of net.py:229-262; lam, gam* are (N,M) like tau."""
+    u, z_prev, lam, gam1 = _dev(u, "u"), _dev(z_prev, "z_prev"), _dev(lam, "lam"), _dev(gam1, "gam1")
+    z_after, gam2 = _opt(z_after, "z_after"), _opt(gam2, "gam2")
+    for name, t in (("u", u), ("z_prev", z_prev), ("z_after", z_after)):
+        if t is not None and tuple(t.shape) != g.code_shape():
+            raise ValueError(f"{name}: shape {tuple(t.shape)} is not the code shape {g.code_shape()}")
+    for name, t in (("lam", lam), ("gam1", gam1), ("gam2", gam2)):
+        if t is not None and t.numel() != g.N * g.M:
+            raise ValueError(f"{name}: expected {g.N * g.M} per-(sample, channel) thresholds")
+    if out is None:
+        out = torch.empty_like(u)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_prox_csr(ctypes.byref(gs), _ptr(u), _ptr(z_prev), _ptr(z_after), _ptr(lam), _ptr(gam1),
+                                 _ptr(gam2), _ptr(out), _stream())
+    _lib.check(rc, "cdl_prox_csr")
+    return out
+
+
+def prox_csr_bwd(g: Geometry, gz, u, z_prev, lam, gam1, c, dlam, dgam1, z_after=None, gam2=None, dgam2=None,
+                 gz_prev=None, gz_after=None, out=None):
+    """Reverse of prox_csr: returns gu; accumulates into gz_prev / gz_after; writes the (2,M) slices
+    dlam, dgam1[, dgam2] of the threshold gradients of this iteration."""
+    gz, u, z_prev = _dev(gz, "gz"), _dev(u, "u"), _dev(z_prev, "z_prev")
+    z_after, gam2, c = _opt(z_after, "z_after"), _opt(gam2, "gam2"), _opt(c, "c")
+    for t in (dlam, dgam1, dgam2):
+        assert t is None or (t.is_contiguous() and t.numel() == 2 * g.M)
+    for t in (gz_prev, gz_after):
+        assert t is None or (t.is_contiguous() and tuple(t.shape) == g.code_shape())
+    if out is None:
+        out = torch.empty_like(gz)
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_prox_csr_scratch_floats(ctypes.byref(gs)))
+    scratch = torch.empty(n, device=gz.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_prox_csr_bwd(ctypes.byref(gs), _ptr(gz), _ptr(u), _ptr(z_prev), _ptr(z_after),
+                                     _ptr(_dev(lam, "lam")), _ptr(_dev(gam1, "gam1")), _ptr(gam2), _ptr(c),
+                                     _ptr(out), _ptr(gz_prev), _ptr(gz_after), _ptr(dlam), _ptr(dgam1),
+                                     _ptr(dgam2), _ptr(scratch), n, _stream())
+    _lib.check(rc, "cdl_prox_csr_bwd")
+    return out
+
+
 def project_filters_(w):
     """In-place unit-ball projection of every (m,c) filter of w (M,C,*P)."""
     if not w.is_cuda:

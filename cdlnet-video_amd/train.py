@@ -9,7 +9,7 @@ plotting are outside the hot path and are not re-implemented here.
 import torch
 import torch.nn as nn
 
-from .net import CDLNet, CDLNetVideo, GDLNet
+from .net import CDLNet, CDLNet_CSR, CDLNet_CSRf2, CDLNetVideo, GDLNet
 from .utils import awgn, gen_bayer_mask
 
 MODEL_TYPES = {
@@ -17,6 +17,8 @@ MODEL_TYPES = {
     "JDD_CDLNet": CDLNet,          # BASELINE config 4: CDLNet with C=3 + Bayer mask
     "CDLNetVideo": CDLNetVideo,
     "GDLNet": GDLNet,
+    "CDLNet_CSR": CDLNet_CSR,      # traincsr.py:290-296
+    "CDLNet_CSRf2": CDLNet_CSRf2,
 }
 
 

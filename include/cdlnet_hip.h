@@ -110,6 +110,31 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g);
 int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c /*N, nullable*/,
                  float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*N*M*/, void *stream);
 
+/* ---- CSR temporal variants --------------------------------------
+ * prox_CSR / prox_CSR_f2 of model/net.py:229-262, the shrinkage that CDLNet_CSR.forward
+ * (net.py:438-455) and CDLNet_CSRf2.forward (net.py:545-563) apply instead of ST when a neighbour
+ * frame's code is supplied.  u, z_prev, z_after, out are fat (N,M,D/sd,H/sh,W/sw); lam, gam1, gam2 are
+ * per (sample, channel) like tau (N*M, from cdl_thresholds).  z_after == NULL selects
+ *   out = ST(ST(u - z_prev - lam*sign(z_prev), lam*gam1) + z_prev + lam*sign(z_prev), lam)
+ * and z_after != NULL the three-level map with both neighbours.  The reference's evaluation order is
+ * kept term by term (no fma): the maps are discontinuous for negative thresholds.  out may alias u. */
+int cdl_prox_csr(const cdl_geom *g, const float *u, const float *z_prev, const float *z_after /*nullable*/,
+                 const float *lam, const float *gam1, const float *gam2 /*nullable iff z_after is*/,
+                 float *out, void *stream);
+
+/* Reverse of cdl_prox_csr as autograd differentiates the reference expression (sign() has zero
+ * gradient): gu = dL/du (may alias gz); gz_prev / gz_after (nullable) are ACCUMULATED into, because a
+ * neighbour code feeds all K iterations; dlam, dgam1, dgam2 are (2,M) and receive
+ * [sum_n s, sum_n c[n]*s] of the per-(n,m) threshold sums, i.e. the gradients of t[k], g1[k], g2[k]
+ * under lam = t[k,0] + c*t[k,1] (net.py:444).  scratch: cdl_prox_csr_scratch_floats(g) floats. */
+int cdl_prox_csr_bwd(const cdl_geom *g, const float *gz, const float *u, const float *z_prev,
+                     const float *z_after /*nullable*/, const float *lam, const float *gam1,
+                     const float *gam2 /*nullable*/, const float *c /*N, nullable*/, float *gu,
+                     float *gz_prev /*nullable*/, float *gz_after /*nullable*/, float *dlam /*2*M*/,
+                     float *dgam1 /*2*M*/, float *dgam2 /*2*M, nullable*/, float *scratch,
+                     size_t scratch_floats, void *stream);
+size_t cdl_prox_csr_scratch_floats(const cdl_geom *g);
+
 /* model/solvers.py:24-28 (uball_project) applied by net.py:72-73,189-190: every filter
  * (consecutive `flen` floats) with l2 norm > 1 is scaled onto the unit sphere.  w inout. */
 int cdl_project_filters(float *w, int nfilters, int flen, void *stream);

@@ -25,6 +25,8 @@ Reference lines restated (all relative to /root/reference):
   awgn / bayer_mask     utils.py:13-55
   train_step            train.py:76-102, train3d.py:90-116
   psnr                  analyze.py:104, analyze3d.py:131-133
+  prox_csr / prox_csr_f2  model/net.py:229-262
+  ista_csr              model/net.py:426-463 (CDLNet_CSR.forward), 525-568 (CDLNet_CSRf2.forward)
 """
 import math
 
@@ -169,6 +171,64 @@ def ista(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, ndim=2, gab
     xp = synthesis(codes[-1], B[0], s, pad)          # D is B[0] (net.py:34)
     xhat = postprocess(xp, mean, pads)
     return (xhat, codes) if all_codes else (xhat, codes[-1])
+
+
+# --------------------------------------------------------------------------- CSR temporal variants
+def prox_csr(u, z_prev, lam, gam):
+    """Two nested shrinkages around the neighbour frame's code (net.py:229-242).  The evaluation
+    order is the reference's, term by term: the maps are discontinuous for negative thresholds, so a
+    re-association that moves a value across 0 by one ulp changes the result by |threshold|."""
+    ls = lam * torch.sign(z_prev)
+    return soft_threshold(soft_threshold(u - z_prev - ls, lam * gam) + z_prev + ls, lam)
+
+
+def prox_csr_f2(u, z_prev, z_after, lam, gam1, gam2):
+    """Three nested shrinkages around both neighbour codes (net.py:244-262), reference order."""
+    ca = z_prev + lam * torch.sign(z_prev) + lam * gam2 * torch.sign(z_prev - z_after)
+    cb = z_after + lam * torch.sign(z_after) + lam * gam1 * torch.sign(z_after - z_prev)
+    inner = soft_threshold(u - ca, gam1 * lam)
+    mid = soft_threshold(inner - cb + lam * gam1 * torch.sign(u - ca), gam2 * lam)
+    return soft_threshold(mid + cb - lam * gam1 * torch.sign(u - ca), lam)
+
+
+def ista_csr(sd, y, z_prev=None, z_after=None, *, K, P, s=1, sigma=None, adaptive=False, mask=None,
+             variant="csr"):
+    """CDLNet_CSR.forward (variant "csr": A2/B2/t2 when there is no neighbour, else A/B/t/g) and
+    CDLNet_CSRf2.forward (variant "f2": one bank, thresholds t/g1/g2, four branches).  Returns
+    (xhat, z_K); D is B[0] in every branch (net.py:386, 460)."""
+    yp, mean, pads, mask_p = preprocess(y, s, mask)
+    c = 0.0 if (sigma is None or not adaptive) else sigma / 255.0
+    pad = _conv_pad(P, 2)
+    A, B = _weights_from_state(sd, K)
+    t = sd["t"]
+    if variant == "csr":
+        if z_after is not None:
+            raise ValueError("CDLNet_CSR has no z_after")
+        if z_prev is None:
+            A_, B_, t = [sd[f"A2.{k}.weight"] for k in range(K)], [sd[f"B2.{k}.weight"] for k in range(K)], sd["t2"]
+            shrink = lambda u, k: soft_threshold(u, _thresholds(t, k, c))
+        else:
+            A_, B_ = A, B
+            shrink = lambda u, k: prox_csr(u, z_prev, _thresholds(t, k, c), _thresholds(sd["g"], k, c))
+    else:
+        A_, B_ = A, B
+        if z_prev is not None and z_after is not None:
+            shrink = lambda u, k: prox_csr_f2(u, z_prev, z_after, _thresholds(t, k, c),
+                                              _thresholds(sd["g1"], k, c), _thresholds(sd["g2"], k, c))
+        elif z_prev is not None:
+            shrink = lambda u, k: prox_csr(u, z_prev, _thresholds(t, k, c), _thresholds(sd["g1"], k, c))
+        elif z_after is not None:
+            shrink = lambda u, k: prox_csr(u, z_after, _thresholds(t, k, c), _thresholds(sd["g2"], k, c))
+        else:
+            shrink = lambda u, k: soft_threshold(u, _thresholds(t, k, c))
+    z = shrink(analysis(yp, A_[0], s, pad), 0)
+    for k in range(1, K):
+        resid = synthesis(z, B_[k], s, pad)
+        if mask_p is not None:
+            resid = mask_p * resid
+        z = shrink(z - analysis(resid - yp, A_[k], s, pad), k)
+    xhat = postprocess(synthesis(z, B[0], s, pad), mean, pads)
+    return xhat, z
 
 
 # --------------------------------------------------------------------------- Gabor dictionary

@@ -46,4 +46,5 @@ def golden():
 
 def rel_err(a, b):
     """max|a-b| / max|b| (the parity metric of SURVEY.md 8(d))."""
+    a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

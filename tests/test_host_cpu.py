@@ -163,3 +163,24 @@ def test_data_helpers_match_reference(golden):
     y, sig = cva.awgn(x, 25)
     assert sig == 25 and y.shape == x.shape
     assert abs(cva.psnr(x, x + 0.1) - 20.0) < 1e-4
+
+
+def test_csr_modules_surface():
+    """CDLNet_CSR / CDLNet_CSRf2 (reference model/net.py:363-568): state_dict keys, parameter names and
+    order as in the fixtures generated from the reference; no CPU compute path either."""
+    for name, cls in (("c1_csr_chain", cva.CDLNet_CSR), ("c2_csrf2_chain", cva.CDLNet_CSRf2)):
+        g = load_golden(name)
+        K, M, P, s, C = g["hyper"]
+        net = cls(K=K, M=M, P=P, s=s, C=C, t0=0.0, adaptive=True, init=False)
+        assert list(net.state_dict().keys()) == list(g["sd"].keys())
+        names = [n for n, _ in net.named_parameters()]
+        assert [n for n in names if n in g["grad"]] == list(g["grad"].keys())
+        assert set(names) - set(g["grad"]) <= {"B2.0.weight"}      # never applied: D is B[0] (net.py:383)
+        net.load_state_dict(g["sd"])
+        assert net.D is net.B[0]
+        with pytest.raises(RuntimeError, match="no CPU"):
+            net(torch.rand(1, 1, 16, 16))
+    net = cva.build_model({"type": "CDLNet_CSRf2", "paths": {"ckpt": "c"},      # argscsr.json's shape
+                           "model": {"adaptive": True, "K": 2, "M": 5, "C": 1, "P": 9, "s": 2, "t0": 0,
+                                     "init": True}})
+    assert isinstance(net, cva.CDLNet_CSRf2) and net.g1.shape == (2, 2, 5, 1, 1)
