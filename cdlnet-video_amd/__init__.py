@@ -7,13 +7,14 @@ from . import _lib, ops, parallel, train, utils
 from ._lib import HipKernelError, HipLibraryMissing
 from .gabor import ConvAdjoint2dGabor
 from .net import ST, CDLNet, CDLNet_CSR, CDLNet_CSRf2, CDLNetVideo, GDLNet, prox_CSR, prox_CSR_f2
+from .temporal import csr_inference_loop, csr_inference_v2
 from .train import build_model, init_model, load_ckpt, save_ckpt, train_step
 from .utils import awgn, awgn3d, gen_bayer_mask, psnr
 
 JDD_CDLNet = CDLNet      # BASELINE.json config 4: CDLNet(C=3) + Bayer mask
 
 __all__ = ["CDLNet", "CDLNetVideo", "GDLNet", "JDD_CDLNet", "CDLNet_CSR", "CDLNet_CSRf2", "prox_CSR",
-           "prox_CSR_f2", "ConvAdjoint2dGabor", "ST",
+           "prox_CSR_f2", "csr_inference_loop", "csr_inference_v2", "ConvAdjoint2dGabor", "ST",
            "build_model", "init_model", "load_ckpt", "save_ckpt", "train_step",
            "awgn", "awgn3d", "gen_bayer_mask", "psnr", "ops", "parallel", "train", "utils",
            "HipLibraryMissing", "HipKernelError"]

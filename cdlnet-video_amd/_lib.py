@@ -43,6 +43,7 @@ SIGNATURES = {
     "cdl_shrink": [_P, _P, _P, _I, ctypes.c_size_t, _P],
     "cdl_analysis": [_G, _P, _P, _F, _P, _P, _P, _P, _P],
     "cdl_synthesis": [_G, _P, _P, _P, _F, _P, _P, _P, _P],
+    "cdl_synthesis_ws": [_G, _P, _P, _P, _F, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_prox_csr": [_G, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -63,7 +64,8 @@ SIGNATURES = {
 }
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
-                "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G]}
+                "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
+                "cdl_synthesis_workspace_floats": [_G]}
 
 _lib = None
 

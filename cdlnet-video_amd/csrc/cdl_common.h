@@ -40,6 +40,8 @@ static inline bool cdl_geom_ok(const cdl_geom *g)
 int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                        const float *gate, const float *tau, float *out, void *stream);
 int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
-                        const float *mask, const float *sub, float *out, void *stream);
+                        const float *mask, const float *sub, float *out, float *ws, size_t ws_floats,
+                        void *stream);
+size_t cdl_tiled_synthesis_ws_floats(const cdl_geom *g);
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
                     float *dw, float *workspace, size_t workspace_floats, void *stream);

@@ -543,12 +543,26 @@ int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha,
     return 0;
 }
 
+size_t cdl_synthesis_workspace_floats(const cdl_geom *g)
+{
+    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
+    return cdl_tiled_synthesis_ws_floats(g);
+}
+
 int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                   const float *mask, const float *sub, float *out, void *stream)
 {
+    return cdl_synthesis_ws(g, z, gate, w, alpha, mask, sub, out, nullptr, 0, stream);
+}
+
+int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                     const float *mask, const float *sub, float *out, float *workspace,
+                     size_t workspace_floats, void *stream)
+{
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
-        const int rc = cdl_tiled_synthesis(g, z, gate, w, alpha, mask, sub, out, stream);
+        const int rc = cdl_tiled_synthesis(g, z, gate, w, alpha, mask, sub, out, workspace, workspace_floats,
+                                           stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }
     const int tilesX = (g->W + TILE - 1) / TILE, tilesY = (g->H + TILE - 1) / TILE;

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_analysis_t(cdl_geom g, const float *__r
                                                     const float *__restrict__ gate,
                                                     const float *__restrict__ tau,
                                                     float *__restrict__ out, int tilesX, int tilesY,
-                                                    int PH, int PWp)
+                                                    int PH, int PWp, int mper)
 {
     extern __shared__ float patch[];                       // [C][Pd][PH][PWp]
     constexpr int WL = (PXT - 1) * SW + PW;                // row window per thread
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_analysis_t(cdl_geom g, const float *__r
 
     const int taps = g.Pd * g.Ph * PW, wrow = g.C * taps;
     const float *pbase = patch + (ly * g.sh) * PWp + lx * PXT * SW;
-    for (int m0 = 0; m0 < g.M; m0 += MCH) {
+    const int m_lo = blockIdx.z * mper, m_hi = min(g.M, m_lo + mper);   // channel slice of this workgroup
+    for (int m0 = m_lo; m0 < m_hi; m0 += MCH) {
         float acc[MCH][PXT];
 #pragma unroll
         for (int j = 0; j < MCH; ++j)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
                                                      const float *__restrict__ mask,
                                                      const float *__restrict__ sub,
                                                      float *__restrict__ out, int tilesX, int tilesY,
-                                                     int PZH, int PZW)
+                                                     int PZH, int PZW, int mper, float *__restrict__ partial)
 {
     extern __shared__ float patch[];                       // [MCH][PZH][PZW]
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
         for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
             for (int p = 0; p < PXT; ++p) acc[cc][p] = 0.0f;
-        for (int m0 = 0; m0 < g.M; m0 += MCH) {
+        const int m_lo = blockIdx.z * mper, m_hi = min(g.M, m_lo + mper);   // channel slice (split launches)
+        for (int m0 = m_lo; m0 < m_hi; m0 += MCH) {
             for (int kd = 0; kd < g.Pd; ++kd) {
                 const int td = d + g.pd - kd;
                 if (td < 0 || td % g.sd) continue;          // uniform
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
                     const int py = r % PZH, mm = r / PZH;
                     const int m = m0 + mm, zy = zy_lo + py, zx = zx_lo + px;
                     float v = 0.0f;
-                    if (m < g.M && zy >= 0 && zy < Hz && zx >= 0 && zx < Wz) {
+                    if (m < m_hi && zy >= 0 && zy < Hz && zx >= 0 && zx < Wz) {
                         const size_t idx = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx;
                         v = z[idx];
                         if (gate && gate[idx] == 0.0f) v = 0.0f;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
                     patch[i] = v;
                 }
                 __syncthreads();
-                const int mlim = min(MCH, g.M - m0);
+                const int mlim = min(MCH, m_hi - m0);
                 for (int ki = 0; ki < g.Ph; ++ki) {
                     const int tyy = y + g.ph - ki + g.sh * g.Ph;      // shifted positive
                     if (tyy % g.sh) continue;                          // same for every row of the wave
@@ -202,6 +204,10 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
                 for (int p = 0; p < PXT; ++p) {
                     const int xo = x0 + p;
                     if (xo >= g.W) continue;
+                    if (partial) {          // split launch: raw channel-slice sum, folded by k_synth_fold
+                        partial[(size_t)blockIdx.z * ((size_t)g.N * g.C * g.D * g.H * g.W) + rowi + xo] = acc[cc][p];
+                        continue;
+                    }
                     float v = alpha * acc[cc][p];
                     if (mask) v *= mask[rowi + xo];
                     if (sub) v -= sub[rowi + xo];
@@ -370,7 +376,34 @@ __global__ void k_wgrad_fold(const float *__restrict__ part, float *__restrict__
     dw[i] = alpha * s;
 }
 
+// out = mask * alpha * sum_chunks partial - sub, chunks added in a fixed order
+__global__ void k_synth_fold(const float *__restrict__ part, const float *__restrict__ mask,
+                             const float *__restrict__ sub, float alpha, float *__restrict__ out,
+                             int chunks, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * total + i];
+    float v = alpha * s;
+    if (mask) v *= mask[i];
+    if (sub) v -= sub[i];
+    out[i] = v;
+}
+
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// A launch with few workgroups (single frames, small crops) leaves most of the 256 CUs idle: split the
+// code channels over blockIdx.z until there are about 1024 workgroups.  Returns channels per slice.
+inline int channel_split(int M, long blocks, int *chunks)
+{
+    const int groups = (M + MCH - 1) / MCH;
+    long want = blocks >= 512 ? 1 : (1024 + blocks - 1) / blocks;
+    if (want > groups) want = groups;
+    const int mper = (int)((groups + want - 1) / want) * MCH;
+    *chunks = (M + mper - 1) / mper;
+    return mper;
+}
 
 template <int PW, int SW>
 int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
@@ -387,25 +420,39 @@ int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alp
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
     }
-    dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N);
-    k_analysis_t<PW, SW><<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, PH, PWp);
+    int chunks;
+    const int mper = channel_split(g->M, (long)tilesX * tilesY * Dz * g->N, &chunks);
+    dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N, (unsigned)chunks);
+    k_analysis_t<PW, SW><<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, PH, PWp,
+                                                        mper);
     CDL_LAUNCH_CHECK();
     return 0;
 }
 
 template <int PW, int SW, int CC>
 int launch_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
-                     const float *mask, const float *sub, float *out, void *stream)
+                     const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream)
 {
     const int tilesX = (g->W + TX - 1) / TX, tilesY = (g->H + TY - 1) / TY;
     const int PZH = (TY - 1 + g->Ph - 1) / g->sh + 2;
     const int PZW = (TX - 1 + PW - 1) / SW + 2 + 4;          // + slack for the fixed-length row windows
     const size_t lds = (size_t)MCH * PZH * PZW * sizeof(float);
     if (lds > 64 * 1024) return CDL_EUNSUPPORTED;
-    dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N);
+    int chunks;
+    int mper = channel_split(g->M, (long)tilesX * tilesY * g->D * g->N, &chunks);
+    const size_t total = (size_t)g->N * g->C * g->D * g->H * g->W;
+    if (chunks > 1 && (!ws || ws_floats < (size_t)chunks * total)) {      // no room for the partial sums
+        chunks = 1;
+        mper = g->M;
+    }
+    dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N, (unsigned)chunks);
     k_synthesis_t<PW, SW, CC><<<grid, 256, lds, S(stream)>>>(*g, z, gate, w, alpha, mask, sub, out, tilesX,
-                                                          tilesY, PZH, PZW);
+                                                          tilesY, PZH, PZW, mper, chunks > 1 ? ws : nullptr);
     CDL_LAUNCH_CHECK();
+    if (chunks > 1) {
+        k_synth_fold<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(ws, mask, sub, alpha, out, chunks, total);
+        CDL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -423,15 +470,24 @@ int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float 
     return CDL_EUNSUPPORTED;
 }
 
+size_t cdl_tiled_synthesis_ws_floats(const cdl_geom *g)
+{
+    const int tilesX = (g->W + TX - 1) / TX, tilesY = (g->H + TY - 1) / TY;
+    int chunks;
+    channel_split(g->M, (long)tilesX * tilesY * g->D * g->N, &chunks);
+    return chunks > 1 ? (size_t)chunks * g->N * g->C * g->D * g->H * g->W : 0;
+}
+
 int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
-                        const float *mask, const float *sub, float *out, void *stream)
+                        const float *mask, const float *sub, float *out, float *ws, size_t ws_floats,
+                        void *stream)
 {
     if (g->sw != g->sh || g->pw != g->Pw / 2) return CDL_EUNSUPPORTED;
     if (g->C != 1 && g->C != 3) return CDL_EUNSUPPORTED;
 #define CDL_S(PW_, SW_)                                                                              \
     if (g->Pw == PW_ && g->sw == SW_)                                                                \
-        return g->C == 1 ? launch_synthesis<PW_, SW_, 1>(g, z, gate, w, alpha, mask, sub, out, stream) \
-                         : launch_synthesis<PW_, SW_, 3>(g, z, gate, w, alpha, mask, sub, out, stream)
+        return g->C == 1 ? launch_synthesis<PW_, SW_, 1>(g, z, gate, w, alpha, mask, sub, out, ws, ws_floats, stream) \
+                         : launch_synthesis<PW_, SW_, 3>(g, z, gate, w, alpha, mask, sub, out, ws, ws_floats, stream)
     CDL_S(3, 1); CDL_S(5, 1); CDL_S(7, 1); CDL_S(9, 1);
     CDL_S(3, 2); CDL_S(5, 2); CDL_S(7, 2); CDL_S(9, 2);
 #undef CDL_S

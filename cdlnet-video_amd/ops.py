@@ -208,13 +208,24 @@ def synthesis(g: Geometry, z, w, alpha=1.0, gate=None, mask=None, sub=None, out=
     if out is None:
         out = torch.empty(g.image_shape(), device=z.device, dtype=torch.float32)
     gs = g.c_struct()
-    rc = _lib.lib().cdl_synthesis(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(w), float(alpha),
-                                  _ptr(mask), _ptr(sub), _ptr(out), _stream())
-    _lib.check(rc, "cdl_synthesis")
+    n = int(_lib.lib().cdl_synthesis_workspace_floats(ctypes.byref(gs)))
+    ws = _scratch(z.device, n) if n else None
+    rc = _lib.lib().cdl_synthesis_ws(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(w), float(alpha),
+                                     _ptr(mask), _ptr(sub), _ptr(out), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_synthesis_ws")
     return out
 
 
 _WGRAD_WS = {}
+_SCRATCH = {}
+
+
+def _scratch(device, n):
+    """One grow-only scratch buffer per device for kernels that need transient partial sums."""
+    buf = _SCRATCH.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _SCRATCH[device] = torch.empty(n, device=device, dtype=torch.float32)
+    return buf
 
 
 def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):

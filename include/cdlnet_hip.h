@@ -94,6 +94,14 @@ int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate /*nullabl
                   const float *w, float alpha, const float *mask /*nullable*/,
                   const float *sub /*nullable*/, float *out, void *stream);
 
+/* cdl_synthesis with scratch for launches too small to fill the GPU (single frames, crops): the code
+ * channels are then split over extra workgroups whose partial images (cdl_synthesis_workspace_floats(g)
+ * floats, 0 when no split is worthwhile) are added in a fixed order.  workspace == NULL: no split. */
+int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                     const float *mask, const float *sub, float *out, float *workspace,
+                     size_t workspace_floats, void *stream);
+size_t cdl_synthesis_workspace_floats(const cdl_geom *g);
+
 /* ---- filter gradients (autograd of the two conv calls above; train.py:98) --------------------
  *   dw[m,c,kd,ki,kj] = alpha * sum_{n,zd,zy,zx} zg[n,m,zd,zy,zx] * x[n,c,zd*sd-pd+kd, zy*sh-ph+ki, zx*sw-pw+kj]
  * with zg = gate ? [gate!=0]*z : z.  dA_k: (z=g_{k+1}, gate=z_{k+1}, x=r_k, alpha=-1);

@@ -210,3 +210,53 @@ def test_csr_masked_frame_vs_oracle():
     (torch.mean((x.cuda() - xh) ** 2) + 0.05 * z.abs().mean()).backward()
     for pname, p in net.named_parameters():
         check(f"f2 masked grad {pname}", p.grad, leaves[pname].grad, GTOL)
+
+
+# ---------------------------------------------------------------------------------- recurrent drivers
+def _clip(T, shape, seed):
+    import cdlnet_video_amd as cva
+    vid = cva.utils.synthetic_clip((1, 1, T) + shape, seed=seed)           # (1,1,T,H,W): frames drift
+    gen = torch.Generator().manual_seed(seed + 1)
+    return [vid[:, :, t] + torch.randn(vid[:, :, t].shape, generator=gen) * 25 / 255 for t in range(T)], vid
+
+
+def test_recurrent_loop_csr_vs_oracle():
+    """analyzemri.py:87-156 call sequence; the oracle replays it with ista_csr."""
+    import cdlnet_video_amd as cva
+    g = load_golden("c1_csr_chain")
+    net = build(g, "CDLNet_CSR")
+    K, M, P, s, C = g["hyper"]
+    frames, vid = _clip(5, (28, 36), 11)
+    kw = dict(K=K, P=P, s=s, sigma=25.0, adaptive=True, variant="csr")
+    with torch.no_grad():
+        _, zp = O.ista_csr(g["sd"], frames[0], None, **kw)
+        _, zc = O.ista_csr(g["sd"], frames[1], zp, **kw)
+        first, zp = O.ista_csr(g["sd"], frames[0], zc, **kw)
+        ref = [first]
+        for t in range(1, 5):
+            xh, zp = O.ista_csr(g["sd"], frames[t], zp, **kw)
+            ref.append(xh)
+    got = cva.csr_inference_loop(net, [f.cuda() for f in frames], 25.0)
+    assert len(got) == 5
+    for t in range(5):
+        check(f"recurrent loop frame {t}", got[t], ref[t], XTOL)
+        assert round(O.psnr(vid[:, :, t], ref[t]), 2) == round(O.psnr(vid[:, :, t], got[t].cpu()), 2)
+
+
+def test_recurrent_v2_csrf2_vs_oracle():
+    """analyzemri.py:162-182: causal pass recording codes, then the two-neighbour pass."""
+    import cdlnet_video_amd as cva
+    g = load_golden("c2_csrf2_chain")
+    net = build(g, "CDLNet_CSRf2")
+    K, M, P, s, C = g["hyper"]
+    T = 4
+    frames, vid = _clip(T, (26, 30), 17)
+    kw = dict(K=K, P=P, s=s, sigma=25.0, adaptive=True, variant="f2")
+    with torch.no_grad():
+        codes = [None] * (T + 2)
+        for t in range(T):
+            _, codes[t + 1] = O.ista_csr(g["sd"], frames[t], codes[t], None, **kw)
+        ref = [O.ista_csr(g["sd"], frames[t], codes[t], codes[t + 1], **kw)[0] for t in range(T)]
+    got = cva.csr_inference_v2(net, [f.cuda() for f in frames], 25.0)
+    for t in range(T):
+        check(f"recurrent v2 frame {t}", got[t], ref[t], XTOL)

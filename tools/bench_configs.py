@@ -108,7 +108,67 @@ def run(name):
     print(json.dumps(out), flush=True)
 
 
+def run_csr(name):
+    """argscsr.json: CDLNet_CSRf2 K=30 M=169 P=9 s=2.  Inference = analyzemri.py:162-182 (two network
+    calls per frame) over a T-frame clip; training = the five-call chain of traincsr.py:257-261 on
+    128x128 crops, batch 1, loss.backward()."""
+    torch.manual_seed(1)
+    kw = dict(K=30, M=169, P=9, s=2, C=1)
+    net = cva.CDLNet_CSRf2(**kw, t0=5e-3, adaptive=True, init=True)
+    with torch.no_grad():
+        net.g1.fill_(0.5)
+        net.g2.fill_(0.5)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    T, H, W = 8, 256, 256
+    vid = cva.utils.synthetic_clip((1, 1, T, H, W), seed=3)
+    gen = torch.Generator().manual_seed(4)
+    frames = [vid[:, :, t] + torch.randn(1, 1, H, W, generator=gen) * 25 / 255 for t in range(T)]
+    fd = [f.cuda() for f in frames]
+    inf_ms = ev(lambda: cva.csr_inference_v2(net, fd, 25.0), 3)
+    out = [o.cpu() for o in cva.csr_inference_v2(net, fd, 25.0)]
+
+    crops = [f[..., :128, :128].contiguous() for f in fd[:3]]
+    clean = [vid[:, :, t, :128, :128].cuda() for t in range(3)]
+    mse = lambda a, b: torch.mean((a - b) ** 2)
+
+    def chain():
+        for p in net.parameters():
+            p.grad = None
+        xp, zp = net(crops[0], None, None, 25.0)
+        xc, zc = net(crops[1], zp, None, 25.0)
+        xa, za = net(crops[2], zc, None, 25.0)
+        xc2, _ = net(crops[1], zp, za, 25.0)
+        xp2, _ = net(crops[0], None, za, 25.0)
+        (mse(clean[0], xp) + mse(clean[1], xc) + mse(clean[2], xa) + mse(clean[1], xc2) + mse(clean[0], xp2)).backward()
+
+    trn_ms = ev(chain, 3)
+
+    torch.set_num_threads(host_cores())
+    okw = dict(K=30, P=9, s=2, sigma=25.0, adaptive=True, variant="f2")
+    Tc = 2
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        codes = [None] * (Tc + 2)
+        for t in range(Tc):
+            _, codes[t + 1] = O.ista_csr(sd, frames[t], codes[t], None, **okw)
+        ref = [O.ista_csr(sd, frames[t], codes[t], codes[t + 1], **okw)[0] for t in range(Tc)]
+        cpu_s = time.perf_counter() - t0
+    got2 = [o.cpu() for o in cva.csr_inference_v2(net, fd[:Tc], 25.0)]
+    rel = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got2, ref))
+    print(json.dumps({
+        "config": name, "model": f"CDLNet_CSRf2 {kw}", "clip": [T, H, W],
+        "inference": "csr_inference_v2 (2 network calls per frame)", "fused_path": False,
+        "infer_ms_per_clip": round(inf_ms, 2), "infer_frames_s": round(T / inf_ms * 1e3, 2),
+        "infer_mpix_s": round(T * H * W / inf_ms / 1e3, 3),
+        "train_chain_ms": round(trn_ms, 2), "train_chain": "5 calls, 128x128 crops, batch 1, fwd+bwd",
+        "cpu_infer_mpix_s": round(Tc * H * W / cpu_s / 1e6, 4), "cpu_threads": torch.get_num_threads(),
+        "cpu_sample": f"{Tc} frames", "xhat_rel_err": rel,
+        "psnr_cpu": round(O.psnr(vid[:, :, 1], ref[1]), 4), "psnr_gpu": round(O.psnr(vid[:, :, 1], got2[1]), 4),
+        "psnr_noisy": round(O.psnr(vid[:, :, 1], frames[1]), 3)}), flush=True)
+
+
 if __name__ == "__main__":
-    for cfg in (sys.argv[1:] or list(CONFIGS)):
+    for cfg in (sys.argv[1:] or list(CONFIGS) + ["csr-f2"]):
         print(f"[{cfg}] ...", file=sys.stderr, flush=True)
-        run(cfg)
+        run_csr(cfg) if cfg == "csr-f2" else run(cfg)
