@@ -17,6 +17,69 @@ __device__ __forceinline__ float cdl_shrink(float u, float t)
     return u > 0.0f ? m : (u < 0.0f ? -m : 0.0f);
 }
 
+// ---- CSR proximal maps (reference model/net.py:229-262), shared by cdl_prox.hip and the analysis
+// epilogues.  The reference's evaluation order is kept term by term and fma contraction is off: the
+// maps are discontinuous for negative thresholds, a one-ulp re-association can move an output by |t|.
+__device__ __forceinline__ float cdl_sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+struct cdl_prox1 {           // intermediates of prox_CSR(u, zp, lam, gam)
+    float s, ls, a, tg, m, z;
+};
+
+__device__ __forceinline__ cdl_prox1 cdl_prox_csr1(float u, float zp, float lam, float gam)
+{
+#pragma clang fp contract(off)
+    cdl_prox1 p;
+    p.s = cdl_sgn(zp);
+    p.ls = lam * p.s;
+    p.a = (u - zp) - p.ls;                                   // u - z_prev - lambd*sign(z_prev)
+    p.tg = lam * gam;
+    const float inner = cdl_shrink(p.a, p.tg);
+    p.m = (inner + zp) + p.ls;
+    p.z = cdl_shrink(p.m, lam);
+    return p;
+}
+
+struct cdl_prox2 {           // intermediates of prox_CSR_f2(u, zp, za, lam, g1, g2)
+    float sp, sa_, spa, sap, a, sa, t1, b, t2, m, z;
+};
+
+__device__ __forceinline__ cdl_prox2 cdl_prox_csr2(float u, float zp, float za, float lam, float g1, float g2)
+{
+#pragma clang fp contract(off)
+    cdl_prox2 p;
+    p.sp = cdl_sgn(zp);
+    p.sa_ = cdl_sgn(za);
+    p.spa = cdl_sgn(zp - za);
+    p.sap = cdl_sgn(za - zp);
+    const float l1 = lam * g1, l2 = lam * g2;
+    const float ca = (zp + lam * p.sp) + l2 * p.spa;
+    const float cb = (za + lam * p.sa_) + l1 * p.sap;
+    p.a = u - ca;
+    p.sa = cdl_sgn(p.a);
+    p.t1 = g1 * lam;
+    const float inner = cdl_shrink(p.a, p.t1);
+    p.b = (inner - cb) + l1 * p.sa;
+    p.t2 = g2 * lam;
+    const float mid = cdl_shrink(p.b, p.t2);
+    p.m = (mid + cb) - l1 * p.sa;
+    p.z = cdl_shrink(p.m, lam);
+    return p;
+}
+
+// Optional CSR epilogue of the analysis kernels: out = prox(u; zp[, za]) and, for training, u itself.
+struct cdl_prox_args {
+    const float *zp, *za, *lam, *g1, *g2;   // zp == nullptr: epilogue off
+    float *u_out;                           // nullable
+};
+
+__device__ __forceinline__ float cdl_prox_apply(const cdl_prox_args &px, float u, size_t idx, int row)
+{
+    if (px.u_out) px.u_out[idx] = u;
+    return px.za ? cdl_prox_csr2(u, px.zp[idx], px.za[idx], px.lam[row], px.g1[row], px.g2[row]).z
+                 : cdl_prox_csr1(u, px.zp[idx], px.lam[row], px.g1[row]).z;
+}
+
 __host__ __device__ __forceinline__ int cdl_floordiv(int a, int b)
 {
     int q = a / b;
@@ -38,7 +101,7 @@ static inline bool cdl_geom_ok(const cdl_geom *g)
 
 // register-tiled variants (cdl_generic_tiled.hip): CDL_EUNSUPPORTED means "use the untiled kernel"
 int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
-                       const float *gate, const float *tau, float *out, void *stream);
+                       const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream);
 int cdl_tiled_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                         const float *mask, const float *sub, float *out, float *ws, size_t ws_floats,
                         void *stream);

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_analysis(cdl_geom g, const float *__res
                                                   const float *__restrict__ zin,
                                                   const float *__restrict__ gate,
                                                   const float *__restrict__ tau,
-                                                  float *__restrict__ out, int tilesX, int tilesY)
+                                                  float *__restrict__ out, int tilesX, int tilesY, cdl_prox_args px)
 {
     extern __shared__ float patch[];
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_analysis(cdl_geom g, const float *__res
                         if (gate && gate[idx] == 0.0f) base = 0.0f;
                     }
                     float u = fmaf(alpha, acc[j], base);
-                    out[idx] = tau ? cdl_shrink(u, tau[n * g.M + m]) : u;
+                    out[idx] = px.zp ? cdl_prox_apply(px, u, idx, n * g.M + m)
+                                     : (tau ? cdl_shrink(u, tau[n * g.M + m]) : u);
                 }
             }
         }
@@ -517,14 +518,33 @@ int cdl_shrink(const float *x, const float *tau, float *out, int rows, size_t pe
     return 0;
 }
 
+static int analysis_impl(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream);
+
 int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                  const float *gate, const float *tau, float *out, void *stream)
+{
+    return analysis_impl(g, x, w, alpha, zin, gate, tau, out, cdl_prox_args{}, stream);
+}
+
+int cdl_analysis_prox(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                      const float *z_prev, const float *z_after, const float *lam, const float *gam1,
+                      const float *gam2, float *u_out, float *out, void *stream)
+{
+    if (!z_prev || !lam || !gam1 || (z_after && !gam2)) return CDL_EINVAL;
+    if (u_out && (u_out == out || u_out == zin)) return CDL_EINVAL;
+    const cdl_prox_args px{z_prev, z_after, lam, gam1, gam2, u_out};
+    return analysis_impl(g, x, w, alpha, zin, nullptr, nullptr, out, px, stream);
+}
+
+static int analysis_impl(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream)
 {
     if (!cdl_geom_ok(g) || !x || !w || !out) return CDL_EINVAL;
     if (out == zin) return CDL_EINVAL;
     if (gate && !zin) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
-        const int rc = cdl_tiled_analysis(g, x, w, alpha, zin, gate, tau, out, stream);
+        const int rc = cdl_tiled_analysis(g, x, w, alpha, zin, gate, tau, out, px, stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
@@ -538,7 +558,7 @@ int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha,
         if (e != hipSuccess) return -(int)e;
     }
     dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N);
-    k_analysis<<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY);
+    k_analysis<<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, px);
     CDL_LAUNCH_CHECK();
     return 0;
 }

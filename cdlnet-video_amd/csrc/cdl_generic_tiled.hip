@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_analysis_t(cdl_geom g, const float *__r
                                                     const float *__restrict__ gate,
                                                     const float *__restrict__ tau,
                                                     float *__restrict__ out, int tilesX, int tilesY,
-                                                    int PH, int PWp, int mper)
+                                                    int PH, int PWp, int mper, cdl_prox_args px)
 {
     extern __shared__ float patch[];                       // [C][Pd][PH][PWp]
     constexpr int WL = (PXT - 1) * SW + PW;                // row window per thread
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_analysis_t(cdl_geom g, const float *__r
                         if (gate && gate[rowi + zx] == 0.0f) base = 0.0f;
                     }
                     const float u = fmaf(alpha, acc[j][p], base);
-                    out[rowi + zx] = tau ? cdl_shrink(u, t) : u;
+                    out[rowi + zx] = px.zp ? cdl_prox_apply(px, u, rowi + zx, n * g.M + m) : (tau ? cdl_shrink(u, t) : u);
                 }
             }
         }
@@ -407,7 +407,7 @@ inline int channel_split(int M, long blocks, int *chunks)
 
 template <int PW, int SW>
 int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
-                    const float *gate, const float *tau, float *out, void *stream)
+                    const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream)
 {
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     const int tilesX = (Wz + TX - 1) / TX, tilesY = (Hz + TY - 1) / TY;
@@ -424,7 +424,7 @@ int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alp
     const int mper = channel_split(g->M, (long)tilesX * tilesY * Dz * g->N, &chunks);
     dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N, (unsigned)chunks);
     k_analysis_t<PW, SW><<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, PH, PWp,
-                                                        mper);
+                                                        mper, px);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -460,10 +460,10 @@ int launch_synthesis(const cdl_geom *g, const float *z, const float *gate, const
 
 // Returns CDL_EUNSUPPORTED when the shape has no tiled instantiation (the caller falls back).
 int cdl_tiled_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
-                       const float *gate, const float *tau, float *out, void *stream)
+                       const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream)
 {
     if (g->sw != g->sh) return CDL_EUNSUPPORTED;
-#define CDL_A(PW_, SW_) if (g->Pw == PW_ && g->sw == SW_) return launch_analysis<PW_, SW_>(g, x, w, alpha, zin, gate, tau, out, stream)
+#define CDL_A(PW_, SW_) if (g->Pw == PW_ && g->sw == SW_) return launch_analysis<PW_, SW_>(g, x, w, alpha, zin, gate, tau, out, px, stream)
     CDL_A(3, 1); CDL_A(5, 1); CDL_A(7, 1); CDL_A(9, 1);
     CDL_A(3, 2); CDL_A(5, 2); CDL_A(7, 2); CDL_A(9, 2);
 #undef CDL_A

@@ -11,55 +11,18 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 namespace {
 
-__device__ __forceinline__ float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ float sgn(float x) { return cdl_sgn(x); }
 
 // d ST(x,t) / dx and d ST(x,t) / dt as autograd sees sign(x) * relu(|x| - t)  (sign has zero gradient)
 __device__ __forceinline__ float st_dx(float x, float t) { return (x != 0.0f && fabsf(x) - t > 0.0f) ? 1.0f : 0.0f; }
 __device__ __forceinline__ float st_dt(float x, float t) { return (fabsf(x) - t > 0.0f) ? -sgn(x) : 0.0f; }
 
-struct Prox1 {           // intermediates of prox_CSR(u, zp, lam, gam)
-    float s, ls, a, tg, m, z;
-};
-
-__device__ __forceinline__ Prox1 prox1(float u, float zp, float lam, float gam)
-{
-#pragma clang fp contract(off)
-    Prox1 p;
-    p.s = sgn(zp);
-    p.ls = lam * p.s;
-    p.a = (u - zp) - p.ls;                                   // u - z_prev - lambd*sign(z_prev)
-    p.tg = lam * gam;
-    const float inner = cdl_shrink(p.a, p.tg);
-    p.m = (inner + zp) + p.ls;
-    p.z = cdl_shrink(p.m, lam);
-    return p;
-}
-
-struct Prox2 {           // intermediates of prox_CSR_f2(u, zp, za, lam, g1, g2)
-    float sp, sa_, spa, sap, a, sa, t1, b, t2, m, z;
-};
-
+using Prox1 = cdl_prox1;
+using Prox2 = cdl_prox2;
+__device__ __forceinline__ Prox1 prox1(float u, float zp, float lam, float gam) { return cdl_prox_csr1(u, zp, lam, gam); }
 __device__ __forceinline__ Prox2 prox2(float u, float zp, float za, float lam, float g1, float g2)
 {
-#pragma clang fp contract(off)
-    Prox2 p;
-    p.sp = sgn(zp);
-    p.sa_ = sgn(za);
-    p.spa = sgn(zp - za);
-    p.sap = sgn(za - zp);
-    const float l1 = lam * g1, l2 = lam * g2;
-    const float ca = (zp + lam * p.sp) + l2 * p.spa;
-    const float cb = (za + lam * p.sa_) + l1 * p.sap;
-    p.a = u - ca;
-    p.sa = sgn(p.a);
-    p.t1 = g1 * lam;
-    const float inner = cdl_shrink(p.a, p.t1);
-    p.b = (inner - cb) + l1 * p.sa;
-    p.t2 = g2 * lam;
-    const float mid = cdl_shrink(p.b, p.t2);
-    p.m = (mid + cb) - l1 * p.sa;
-    p.z = cdl_shrink(p.m, lam);
-    return p;
+    return cdl_prox_csr2(u, zp, za, lam, g1, g2);
 }
 
 __global__ __launch_bounds__(256) void k_prox_fwd(const float *__restrict__ u, const float *__restrict__ zp,

@@ -40,6 +40,14 @@ def set_precision(name):
 
 
 def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    """Whole sweep from one C call (cdl_ista_forward): same launches as the stepwise form below."""
+    keep = keep_codes or keep_resid
+    xp, z, codes, resid, _ = ops.ista_forward(g, yp, mask_p, tau, A, B, keep)
+    return xp, z, codes, (resid if keep_resid else [])
+
+
+def _forward_generic_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    """Same sweep driven launch by launch from Python (kept for tests and experiments)."""
     K = len(A)
     codes, resid = [], []
     z = ops.analysis(g, yp, A[0], 1.0, None, None, tau[0])
@@ -83,6 +91,14 @@ def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
 
 
 def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+    """Reverse sweep from one C call (cdl_ista_backward)."""
+    if g_xp is None and g_z is None:
+        return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
+    return ops.ista_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt)
+
+
+def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+    """Same reverse sweep driven launch by launch from Python (kept for tests and experiments)."""
     dA, dB = [None] * K, [None] * K
     zK = codes[K - 1]
     if g_xp is not None:
@@ -198,21 +214,30 @@ class UnrolledISTA(torch.autograd.Function):
 #     u_0 = A_0 yp                       z_1     = prox(u_0; zp[, za], lam_0, gam_0)
 #     u_k = z_k - A_k(mask B_k z_k - yp) z_{k+1} = prox(u_k; ...)
 # The reverse sweep needs u_k (the derivative masks of the nested shrinkages are not recoverable from
-# z_{k+1}), so the training forward keeps u_k next to z_k; everything else is _backward_generic with
-# the gating done by cdl_prox_csr_bwd, which also accumulates the neighbour-code gradients.
+# z_{k+1}), so the training forward keeps u_k next to z_k (both written by the analysis kernel, whose
+# epilogue is the proximal map: cdl_analysis_prox); everything else is _backward_generic with the gating
+# done by cdl_prox_csr_bwd, which also accumulates the neighbour-code gradients.
 def _forward_csr(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep):
+    xp, z, codes, resid, us = ops.ista_forward(g, yp, mask_p, lam, A, B, keep, zp, za, gam1, gam2)
+    return xp, z, us, codes, resid
+
+
+def _forward_csr_stepwise(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep):
     K = len(A)
     us, codes, resid = [], [], []
     g2 = (lambda k: gam2[k]) if za is not None else (lambda k: None)
-    u = ops.analysis(g, yp, A[0], 1.0, None, None, None)
-    z = ops.prox_csr(g, u, zp, lam[0], gam1[0], za, g2(0))
+    new = lambda: torch.empty(g.code_shape(), device=yp.device, dtype=torch.float32)
+    u = new() if keep else None
+    z = ops.analysis_prox(g, yp, A[0], 1.0, None, zp, lam[0], gam1[0], za, g2(0), u_out=u)
+    spare = None if keep else new()                      # inference: z ping-pongs between two buffers
     for k in range(1, K):
         if keep:
             us.append(u)
             codes.append(z)
+            u = new()
         r = ops.synthesis(g, z, B[k], 1.0, None, mask_p, yp)
-        u = ops.analysis(g, r, A[k], -1.0, z, None, None, out=None if keep else u)    # u, z ping-pong
-        z = ops.prox_csr(g, u, zp, lam[k], gam1[k], za, g2(k), out=None if keep else z)
+        z_next = ops.analysis_prox(g, r, A[k], -1.0, z, zp, lam[k], gam1[k], za, g2(k), u_out=u, out=spare)
+        spare, z = (None, z_next) if keep else (z, z_next)
         if keep:
             resid.append(r)
     if keep:
@@ -273,29 +298,13 @@ class TemporalISTA(torch.autograd.Function):
         need_zp, need_za = ctx.needs_input_grad[3], za is not None and ctx.needs_input_grad[4]
         gzp = torch.zeros_like(zp) if need_zp else None
         gza = torch.zeros_like(zp) if need_za else None
-        dA, dB = [None] * K, [None] * K
-        zK = codes[K - 1]
-        if g_xhat is not None:
-            g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads)
-            dB[0] = ops.wgrad(g, zK, g_xp, 1.0)
-            gk = ops.analysis(g, g_xp, B[0], 1.0, g_z.contiguous() if g_z is not None else None, None, None)
+        g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads) if g_xhat is not None else None
+        g_z = g_z.contiguous() if g_z is not None else None
+        if g_xp is None and g_z is None:
+            dA, dB = [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
         else:
-            dB[0] = torch.zeros_like(B[0])
-            gk = g_z.contiguous().clone() if g_z is not None else torch.zeros_like(zK)
-
-        def prox_bwd(k, gk):          # gk (dL/dz_{k+1}) -> dL/du_k, in place
-            return ops.prox_csr_bwd(g, gk, us[k], zp, lam[k], gam1[k], c, dt[k], dg1[k], za,
-                                    gam2[k] if za is not None else None, dg2[k] if za is not None else None,
-                                    gzp, gza, out=gk)
-
-        for k in range(K - 1, 0, -1):
-            gu = prox_bwd(k, gk)
-            q = ops.synthesis(g, gu, A[k], -1.0, None, mask_p, None)
-            dA[k] = ops.wgrad(g, gu, resid[k - 1], -1.0)
-            dB[k] = ops.wgrad(g, codes[k - 1], q, 1.0)
-            gk = ops.analysis(g, q, B[k], 1.0, gu, None, None)
-        gu = prox_bwd(0, gk)
-        dA[0] = ops.wgrad(g, gu, yp, 1.0)
+            dA, dB = ops.ista_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z,
+                                       dt, list(us), zp, za, lam, gam1, gam2, dg1, dg2, gzp, gza)
         return (None, None, None, gzp, gza, dt.reshape(t.shape), dg1.reshape(g1.shape),
                 dg2.reshape(g2.shape) if dg2 is not None else None, None, *dA, *dB)
 

@@ -275,6 +275,26 @@ def prox_csr(g: Geometry, u, z_prev, lam, gam1, z_after=None, gam2=None, out=Non
     return out
 
 
+def analysis_prox(g: Geometry, x, w, alpha, zin, z_prev, lam, gam1, z_after=None, gam2=None, u_out=None, out=None):
+    """cdl_analysis with the CSR map as epilogue: returns z = prox(zin + alpha*corr(x; w)); `u_out`
+    (a code-shaped tensor) receives the pre-shrinkage value when given."""
+    x, w = _dev(x, "x"), _dev(w, "w")
+    zin, z_prev, z_after = _opt(zin, "zin"), _dev(z_prev, "z_prev"), _opt(z_after, "z_after")
+    assert tuple(x.shape) == g.image_shape(), (x.shape, g.image_shape())
+    assert tuple(w.shape) == g.filter_shape(), (w.shape, g.filter_shape())
+    for name, t in (("zin", zin), ("z_prev", z_prev), ("z_after", z_after), ("u_out", u_out)):
+        if t is not None and (tuple(t.shape) != g.code_shape() or not t.is_contiguous()):
+            raise ValueError(f"{name}: expected a contiguous tensor of the code shape {g.code_shape()}")
+    if out is None:
+        out = torch.empty(g.code_shape(), device=x.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_analysis_prox(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin), _ptr(z_prev),
+                                      _ptr(z_after), _ptr(_dev(lam, "lam")), _ptr(_dev(gam1, "gam1")),
+                                      _ptr(_opt(gam2, "gam2")), _ptr(u_out), _ptr(out), _stream())
+    _lib.check(rc, "cdl_analysis_prox")
+    return out
+
+
 def prox_csr_bwd(g: Geometry, gz, u, z_prev, lam, gam1, c, dlam, dgam1, z_after=None, gam2=None, dgam2=None,
                  gz_prev=None, gz_after=None, out=None):
     """Reverse of prox_csr: returns gu; accumulates into gz_prev / gz_after; writes the (2,M) slices
@@ -496,4 +516,68 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
         _ptr(du0), _ptr(du1), _ptr(q), _ptr(frags), _ptr(patches), _ptr(dtp), _ptr(ws), PRECISION[precision],
         _stream())
     _lib.check(rc, "cdl_fused2d_backward")
+    return dA, dB
+
+
+# ------------------------------------------------------------------------------------------
+# whole sweeps of the shape-generic loop (cdl_sweep.hip)
+def _new(shape, device):
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+def ista_scratch(g: Geometry, device):
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_ista_scratch_floats(ctypes.byref(gs)))
+    return _scratch(device, max(n, 1)), n
+
+
+def ista_forward(g: Geometry, yp, mask_p, tau, A, B, keep, z_prev=None, z_after=None, gam1=None, gam2=None):
+    """Generic forward sweep in one C call.  Plain ST loop (z_prev None) or the CSR maps.  keep=True:
+    every z_k, r_k (and u_k for CSR) gets its own buffer.  Returns (xp, z_K, codes, resid, us)."""
+    K = len(A)
+    yp, tau, mask_p = _dev(yp, "yp"), _dev(tau, "tau"), _opt(mask_p, "mask")
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    z_prev, z_after = _opt(z_prev, "z_prev"), _opt(z_after, "z_after")
+    gam1, gam2 = _opt(gam1, "gam1"), _opt(gam2, "gam2")
+    dev = yp.device
+    nz = K if keep else min(K, 2)
+    nr = (K - 1) if keep else min(K - 1, 2)
+    zbuf = [_new(g.code_shape(), dev) for _ in range(nz)]
+    rbuf = [_new(g.image_shape(), dev) for _ in range(nr)]
+    z = [zbuf[k % nz] for k in range(K)]
+    r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
+    u = [_new(g.code_shape(), dev) for _ in range(K)] if (keep and z_prev is not None) else []
+    xp = _new(g.image_shape(), dev)
+    ws, n = ista_scratch(g, dev)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_ista_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr(z_prev),
+                                     _ptr(z_after), _ptr(gam1), _ptr(gam2), _ptr_table(A), _ptr_table(B),
+                                     _ptr_table(z), _ptr_table(r) if r else None, _ptr_table(u) if u else None,
+                                     _ptr(xp), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_ista_forward")
+    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else []), u
+
+
+def ista_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, us=None, z_prev=None,
+                  z_after=None, lam=None, gam1=None, gam2=None, dg1=None, dg2=None, gz_prev=None, gz_after=None):
+    """Generic reverse sweep in one C call; returns (dA, dB) and fills dt [, dg1, dg2, gz_prev, gz_after]."""
+    K = len(A)
+    dev = yp.device
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    dA = [_new(g.filter_shape(), dev) for _ in range(K)]
+    dB = [_new(g.filter_shape(), dev) for _ in range(K)]
+    g0, g1, q = _new(g.code_shape(), dev), _new(g.code_shape(), dev), _new(g.image_shape(), dev)
+    ws, n = ista_scratch(g, dev)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_ista_backward(
+        ctypes.byref(gs), K, _ptr(_dev(yp, "yp")), _ptr(_opt(mask_p, "mask")), _ptr(_opt(c, "c")),
+        _ptr(_opt(z_prev, "z_prev")), _ptr(_opt(z_after, "z_after")), _ptr(_opt(lam, "lam")),
+        _ptr(_opt(gam1, "gam1")), _ptr(_opt(gam2, "gam2")), _ptr_table(A), _ptr_table(B),
+        _ptr_table([_dev(t, "z") for t in codes]), _ptr_table([_dev(t, "r") for t in resid]) if resid else None,
+        _ptr_table([_dev(t, "u") for t in us]) if us else None, _ptr(_opt(g_xp, "g_xp")), _ptr(_opt(g_z, "g_z")),
+        _ptr_table(dA), _ptr_table(dB), _ptr(dt), _ptr(dg1), _ptr(dg2), _ptr(gz_prev), _ptr(gz_after),
+        _ptr(g0), _ptr(g1), _ptr(q), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_ista_backward")
     return dA, dB

@@ -130,6 +130,14 @@ int cdl_prox_csr(const cdl_geom *g, const float *u, const float *z_prev, const f
                  const float *lam, const float *gam1, const float *gam2 /*nullable iff z_after is*/,
                  float *out, void *stream);
 
+/* cdl_analysis with the CSR map as its epilogue (one fat write + read per iteration less than
+ * cdl_analysis followed by cdl_prox_csr):  u = zin + alpha*corr(x ; w),  out = prox(u; z_prev[, z_after]),
+ * and u itself to u_out when it is not NULL (the reverse sweep needs it).  Same bits as the two-call form. */
+int cdl_analysis_prox(const cdl_geom *g, const float *x, const float *w, float alpha,
+                      const float *zin /*nullable*/, const float *z_prev, const float *z_after /*nullable*/,
+                      const float *lam, const float *gam1, const float *gam2 /*nullable*/,
+                      float *u_out /*nullable*/, float *out, void *stream);
+
 /* Reverse of cdl_prox_csr as autograd differentiates the reference expression (sign() has zero
  * gradient): gu = dL/du (may alias gz); gz_prev / gz_after (nullable) are ACCUMULATED into, because a
  * neighbour code feeds all K iterations; dlam, dgam1, dgam2 are (2,M) and receive
@@ -142,6 +150,36 @@ int cdl_prox_csr_bwd(const cdl_geom *g, const float *gz, const float *u, const f
                      float *dgam1 /*2*M*/, float *dgam2 /*2*M, nullable*/, float *scratch,
                      size_t scratch_floats, void *stream);
 size_t cdl_prox_csr_scratch_floats(const cdl_geom *g);
+
+/* ---- whole sweeps of the shape-generic loop in one call ------------------------------------------
+ * The same launches as K x (cdl_synthesis_ws, cdl_analysis | cdl_analysis_prox) + the final synthesis,
+ * resp. the reverse sweep (cdl_tau_grad | cdl_prox_csr_bwd, cdl_synthesis_ws, 2 x cdl_wgrad, cdl_analysis
+ * per iteration), enqueued from C: single frames and crops are launch-bound, a host round trip per
+ * launch would dominate.  Pointer tables are HOST arrays of device pointers.
+ * Forward (net.py:76-92 / 192-212 / 426-463 / 525-568): tau (K,N,M) thresholds (CSR: lam); z_prev NULL =
+ * plain ST loop, else the CSR map with gam1 (K,N,M) [and z_after, gam2]; z[k] receives z_{k+1}, r[k]
+ * receives r_{k+1} (k < K-1), u[k] (CSR, nullable table) receives u_k; entries may alias ping-pong
+ * buffers when nothing is kept, as long as z[k] != z[k-1].  xp receives D z_K.  scratch (nullable):
+ * cdl_ista_scratch_floats(g) floats.
+ * Backward: z, r, u as saved by the forward; g_xp = dL/d(D z_K) and / or g_z = dL/dz_K; writes dA[k],
+ * dB[k], dt (K,2,M) [, dg1, dg2 (K,2,M)], accumulates gz_prev / gz_after (nullable); gbuf0, gbuf1 fat
+ * scratch, q thin scratch, scratch as above (required). */
+size_t cdl_ista_scratch_floats(const cdl_geom *g);
+int cdl_ista_forward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
+                     const float *tau, const float *z_prev /*nullable*/, const float *z_after /*nullable*/,
+                     const float *gam1 /*nullable*/, const float *gam2 /*nullable*/,
+                     const float *const *wA, const float *const *wB, float *const *z, float *const *r,
+                     float *const *u /*nullable*/, float *xp, float *scratch, size_t scratch_floats,
+                     void *stream);
+int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
+                      const float *c /*N, nullable*/, const float *z_prev /*nullable*/,
+                      const float *z_after /*nullable*/, const float *lam, const float *gam1, const float *gam2,
+                      const float *const *wA, const float *const *wB, const float *const *z,
+                      const float *const *r, const float *const *u /*CSR*/, const float *g_xp /*nullable*/,
+                      const float *g_z /*nullable*/, float *const *dA, float *const *dB, float *dt,
+                      float *dg1 /*CSR*/, float *dg2 /*CSR f2*/, float *gz_prev /*nullable*/,
+                      float *gz_after /*nullable*/, float *gbuf0, float *gbuf1, float *q, float *scratch,
+                      size_t scratch_floats, void *stream);
 
 /* model/solvers.py:24-28 (uball_project) applied by net.py:72-73,189-190: every filter
  * (consecutive `flen` floats) with l2 norm > 1 is scaled onto the unit sphere.  w inout. */

@@ -260,3 +260,75 @@ def test_recurrent_v2_csrf2_vs_oracle():
     got = cva.csr_inference_v2(net, [f.cuda() for f in frames], 25.0)
     for t in range(T):
         check(f"recurrent v2 frame {t}", got[t], ref[t], XTOL)
+
+
+@pytest.mark.parametrize("both", [False, True])
+@pytest.mark.parametrize("dims,P,s,C,M", [((24, 40), (5, 5), 1, 1, 11), ((22, 18), (7, 7), 2, 3, 9),
+                                           ((4, 12, 16), (3, 5, 5), 1, 1, 6), ((20, 26), (11, 11), 1, 1, 5)])
+def test_analysis_with_prox_epilogue_equals_two_calls(dims, P, s, C, M, both):
+    """cdl_analysis_prox (tiled and untiled kernels) == cdl_analysis then cdl_prox_csr, bit for bit, and
+    its u_out is the plain analysis output."""
+    from cdlnet_video_amd import ops
+    gen = torch.Generator().manual_seed(len(dims) * 7 + P[-1] + both)
+    N = 2
+    geom = ops.Geometry.make(N, C, M, dims, P, tuple(p // 2 for p in P), s)
+    x = torch.randn(geom.image_shape(), generator=gen).cuda()
+    w = (0.1 * torch.randn(geom.filter_shape(), generator=gen)).cuda()
+    code = lambda: (0.3 * torch.randn(geom.code_shape(), generator=gen)
+                    * (torch.rand(geom.code_shape(), generator=gen) > 0.5)).cuda()
+    zin, zp, za = code(), code(), code()
+    lam, g1, g2 = ((torch.rand(N, M, generator=gen) * sc).cuda() for sc in (0.2, 1.2, 1.2))
+    u_ref = ops.analysis(geom, x, w, -1.0, zin, None, None)
+    z_ref = ops.prox_csr(geom, u_ref, zp, lam, g1, za if both else None, g2 if both else None)
+    u_out = torch.empty_like(u_ref)
+    z = ops.analysis_prox(geom, x, w, -1.0, zin, zp, lam, g1, za if both else None, g2 if both else None, u_out=u_out)
+    assert torch.equal(u_out, u_ref)
+    assert torch.equal(z, z_ref)
+    z2 = ops.analysis_prox(geom, x, w, -1.0, zin, zp, lam, g1, za if both else None, g2 if both else None)
+    assert torch.equal(z2, z_ref)
+
+
+# ---------------------------------------------------------------------------------- whole-sweep C calls
+@pytest.mark.parametrize("dims,P,s,C,M,masked", [((24, 40), (5, 5), 1, 1, 11, False), ((22, 18), (7, 7), 2, 3, 9, True),
+                                                  ((4, 12, 16), (3, 5, 5), 1, 1, 6, False)])
+def test_generic_sweeps_equal_stepwise_launches(dims, P, s, C, M, masked):
+    """cdl_ista_forward / cdl_ista_backward enqueue exactly the launches the stepwise Python loops make:
+    every output is bit-identical, for the plain ST loop and for both CSR maps."""
+    from cdlnet_video_amd import loop, ops
+    gen = torch.Generator().manual_seed(sum(dims) + M)
+    N, K = 2, 3
+    geom = ops.Geometry.make(N, C, M, dims, P, tuple(p // 2 for p in P), s)
+    rnd = lambda shape, sc=1.0: (sc * torch.randn(shape, generator=gen)).cuda()
+    yp = rnd(geom.image_shape())
+    mask = (torch.rand(geom.image_shape(), generator=gen) > 0.3).float().cuda() if masked else None
+    A = [rnd(geom.filter_shape(), 0.08) for _ in range(K)]
+    B = [rnd(geom.filter_shape(), 0.08) for _ in range(K)]
+    c = torch.rand(N, generator=gen).cuda()
+    t, g1, g2 = ((torch.rand(K, 2, M, 1, 1, generator=gen) * sc).cuda() for sc in (0.05, 1.0, 1.0))
+    tau, gam1, gam2 = (ops.thresholds(p, c, N) for p in (t, g1, g2))
+    g_xp, g_z = rnd(geom.image_shape()), rnd(geom.code_shape(), 0.1)
+
+    # plain loop
+    a = loop._forward_generic(geom, yp, mask, tau, A, B, True, True)
+    b = loop._forward_generic_stepwise(geom, yp, mask, tau, A, B, True, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2])) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    dta, dtb = torch.zeros(K, 2, M, device="cuda"), torch.zeros(K, 2, M, device="cuda")
+    ga = loop._backward_generic(geom, K, yp, mask, c, A, B, a[2], a[3], g_xp, g_z, dta)
+    gb = loop._backward_generic_stepwise(geom, K, yp, mask, c, A, B, b[2], b[3], g_xp, g_z, dtb)
+    assert torch.equal(dta, dtb)
+    for x, y in zip(ga[0] + ga[1], gb[0] + gb[1]):
+        assert torch.equal(x, y)
+    inf = loop._forward_generic(geom, yp, mask, tau, A, B, False, False)          # ping-pong buffers
+    assert torch.equal(inf[0], a[0]) and torch.equal(inf[1], a[1])
+
+    # CSR loops (one and two neighbours)
+    zp, za = rnd(geom.code_shape(), 0.2), rnd(geom.code_shape(), 0.2)
+    for zaft, gm2 in ((None, None), (za, gam2)):
+        a = loop._forward_csr(geom, yp, mask, tau, gam1, gm2, zp, zaft, A, B, True)
+        b = loop._forward_csr_stepwise(geom, yp, mask, tau, gam1, gm2, zp, zaft, A, B, True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for la, lb in zip(a[2:], b[2:]):
+            assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb))
+        inf = loop._forward_csr(geom, yp, mask, tau, gam1, gm2, zp, zaft, A, B, False)
+        assert torch.equal(inf[0], a[0]) and torch.equal(inf[1], a[1])
