@@ -70,6 +70,7 @@ struct FusedParams {
     int dbg;                 // timing experiments only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis, 32 no LDS adds, 64 no ST,
                              // 4 no analysis MFMAs, 8 no thin staging, 16 no fat loads; results are wrong
     int N, H, W, tilesX, tilesY;
+    int rev;                 // walk the tiles from the last to the first (see "snake order" at the sweeps)
 };
 
 enum { MODE_FWD = 0, MODE_FIRST = 1, MODE_BWD = 2 };
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     // the image); the pad words stay zero from the pass above.
     float stg[NSTG];
     auto stage_load = [&](int t) {
-        int bid = t;
+        int bid = p.rev ? numTiles - 1 - t : t;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
         const int tyi = bid % p.tilesY;
         const int n = bid / p.tilesY;
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
 #pragma unroll 1
     for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
-    int bid = t;
+    const int tile = p.rev ? numTiles - 1 - t : t;
+    int bid = tile;
     const int txi = bid % p.tilesX; bid /= p.tilesX;
     const int tyi = bid % p.tilesY;
     const int n = bid / p.tilesY;
@@ -602,10 +604,10 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         float sacc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) sacc += tacc_s[w * 64 + tid];
-        p.dtau[(size_t)t * M + tid] = sacc;
+        p.dtau[(size_t)tile * M + tid] = sacc;
     }
     if (MODE != MODE_BWD || p.do_synth) {    // patch out (fixed slab order), slabs re-zeroed for the next tile
-        float *patch = p.patches + (size_t)t * SLAB;
+        float *patch = p.patches + (size_t)tile * SLAB;
         for (int i = tid; i < SLAB; i += NT) {
             patch[i] = (rsum_all[i] + rsum_all[SLAB + i]) + (rsum_all[2 * SLAB + i] + rsum_all[3 * SLAB + i]);
             rsum_all[i] = 0.0f; rsum_all[SLAB + i] = 0.0f; rsum_all[2 * SLAB + i] = 0.0f; rsum_all[3 * SLAB + i] = 0.0f;
@@ -685,6 +687,7 @@ struct WgradParams {
     const float *T[2];       // thin (N,H,W)
     float *partial;          // (gridDim.x, 2, M, 64)
     int N, H, W, tilesX, tilesY, numTiles;
+    int rev;                 // tiles from last to first
 };
 
 template <int MT, int PREC, bool WIDE>
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
     for (int i = tid; i < WG_THIN_BYTES / 16; i += 512) reinterpret_cast<uint4 *>(dsm)[i] = make_uint4(0, 0, 0, 0);
 
     for (int t = blockIdx.x; t < p.numTiles; t += gridDim.x) {
-        int bid = t;
+        int bid = p.rev ? p.numTiles - 1 - t : t;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
         const int tyi = bid % p.tilesY;
         const int n = bid / p.tilesY;
@@ -1070,8 +1073,11 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
+    const int rev = (precision >> 4) & 1;
+    precision &= ~CDL_TILES_REVERSED;
     if (precision != 0 && precision != 1) return CDL_EINVAL;
     FusedParams p = {};
+    p.rev = rev;
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = sgn; p.do_synth = 1; p.dbg = debug_flags();
@@ -1087,8 +1093,11 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!thin || !gate || !frags || !du_out || !dtau_partial || du_out == base || du_out == gate) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
+    const int rev = (precision >> 4) & 1;
+    precision &= ~CDL_TILES_REVERSED;
     if (precision != 0 && precision != 1) return CDL_EINVAL;
     FusedParams p = {};
+    p.rev = rev;
     p.r = thin; p.zin = base; p.gate = gate; p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; p.dbg = debug_flags();
@@ -1120,8 +1129,11 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!workspace || (!X0 && !X1)) return CDL_EINVAL;
     if ((X0 && (!T0 || !dw0)) || (X1 && (!T1 || !dw1))) return CDL_EINVAL;
+    const int rev = (precision >> 4) & 1;
+    precision &= ~CDL_TILES_REVERSED;
     if (precision != 0 && precision != 1) return CDL_EINVAL;
     WgradParams p = {};
+    p.rev = rev;
     p.X[0] = X0; p.T[0] = T0; p.X[1] = X1; p.T[1] = T1;
     p.partial = workspace;
     p.N = g->N; p.H = g->H; p.W = g->W;
@@ -1151,7 +1163,17 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
     return 0;
 }
 
-/* ---- whole sweeps: every launch of a forward / reverse pass enqueued from one C call ---------------- */
+/* ---- whole sweeps: every launch of a forward / reverse pass enqueued from one C call ----------------
+ * Snake order: consecutive fat launches walk the tiles in opposite directions, so each one starts on
+ * the bytes the previous one touched last, which are still in the 256 MiB Infinity Cache (it holds
+ * the last ~256 MiB loaded or stored).  Tile results do not depend on the order; only the filter
+ * gradients' per-workgroup partial sums are grouped differently.  CDL_FUSED_SNAKE=0 turns it off. */
+static int snake_enabled()
+{
+    static const int on = [] { const char *e = getenv("CDL_FUSED_SNAKE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on;
+}
+
 int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
                         const float *const *wA, const float *const *wB, float *const *z, float *const *r,
                         float *xp, void *frags, float *patches, int precision, void *stream)
@@ -1159,12 +1181,13 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
     const size_t nm = (size_t)g->N * g->M;
+    const int snake = snake_enabled();
     const float *thin = yp;
     for (int k = 0; k < K; ++k) {
         int rc = cdl_fused2d_prep(wA[k], wB[(k + 1) % K], frags, g->M, g->Ph, stream);
         if (rc) return rc;
         rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, frags, k ? -1.0f : 1.0f, z[k],
-                                  patches, precision, stream);
+                                  patches, precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
         if (rc) return rc;
         if (k < K - 1) {
             rc = cdl_fused2d_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
@@ -1189,25 +1212,29 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
         return CDL_EINVAL;
     const int M = g->M;
     float *du[2] = {du0, du1};
+    // the forward's last launch ran in direction (K-1)&1: stages take that one, filter gradients the other
+    const int sdir = snake_enabled() ? (((K - 1) & 1) ? CDL_TILES_REVERSED : 0) : 0;
+    const int wdir = snake_enabled() ? (sdir ^ CDL_TILES_REVERSED) : 0;
+    const int sprec = precision | sdir, wprec = precision | wdir;
     int rc = cdl_fused2d_wgrad(g, z[K - 1], g_xp, 1.0f, dB[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
-                               precision, stream);                       // dB_0 = z_K (x) dL/d(D z_K)
+                               wprec, stream);                           // dB_0 = z_K (x) dL/d(D z_K)
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
     for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
         rc = cdl_fused2d_prep(wB[(k + 1) % K], wA[k], frags, M, g->Ph, stream);
         if (rc) return rc;
         float *duk = du[flip];
-        rc = cdl_fused2d_stage_bwd(g, thin, base, z[k], frags, duk, patches, dtau_partial, k >= 1, precision, stream);
+        rc = cdl_fused2d_stage_bwd(g, thin, base, z[k], frags, duk, patches, dtau_partial, k >= 1, sprec, stream);
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
         if (rc) return rc;
         if (k >= 1) {
             rc = cdl_fused2d_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
             if (rc) return rc;
-            rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, precision, stream);
+            rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wprec, stream);
             thin = q;
         } else {
-            rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws, precision, stream);
+            rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws, wprec, stream);
         }
         if (rc) return rc;
         base = duk;

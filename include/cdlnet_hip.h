@@ -196,6 +196,11 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
                           const float *dw, float *dalpha, float *da, float *dw0, float *dpsi,
                           int order, int M, int C, int P, int transpose, void *stream);
 
+/* OR-ed into the `precision` argument of cdl_fused2d_iter_fwd / _stage_bwd / _wgrad: walk the tiles from
+ * the last to the first.  Stage results are identical; the filter gradients' per-workgroup partial sums
+ * are grouped differently (still deterministic).  The whole-sweep entry points alternate it per launch. */
+#define CDL_TILES_REVERSED 16
+
 /* ==== fused MFMA path (cdl_fused2d.hip): 2-D, C = 1, stride 1, odd P <= 7, M in {32, 64} =========
  * One launch per unrolled iteration replaces the whole body of net.py:87
  *     z = ST(z - A_k(mask*B_k(z) - yp), tau_k)
