@@ -1003,7 +1003,11 @@ int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, int precis
 {
     // persistent workgroups: one per CU (128 KB of LDS each), striding over the tiles
     const size_t tiles = (size_t)p.N * p.tilesX * p.tilesY;
-    const size_t cus = (size_t)cu_count();
+    size_t cus = (size_t)cu_count();
+    if (const char *e = getenv("CDL_FUSED_GRID")) {          // experiments only: fewer persistent workgroups
+        const int v = atoi(e);
+        if (v > 0 && (size_t)v < cus) cus = (size_t)v;
+    }
     dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     if (g->M == 64) return precision == 0 ? launch_stage<2, 0>(p, mode, grid, st) : launch_stage<2, 1>(p, mode, grid, st);
     return precision == 0 ? launch_stage<1, 0>(p, mode, grid, st) : launch_stage<1, 1>(p, mode, grid, st);
