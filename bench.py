@@ -104,11 +104,15 @@ def kernel_probe(cva, net, batch, size, reps=5):
         patches = o.fused_patches(g, dev)
         ws = o.fused_wgrad_workspace(g, dev)
         dtp = torch.empty((o.fused_tiles(g), M), device=dev)
+        bits = o.fused_support_map(g, z)             # what the training forward writes next to z' (2 bits/element)
+        mapb = bits.numel() * 4
         table = {
-            f"k_stage<FWD,{prec}> (z'=ST(z-A r), patches of B z')":
-                (lambda: o.fused_iter(g, x, z, tau, frags, -1.0, patches, prec, out=out), K, 2 * fat + 2 * th),
+            f"k_stage<FWD,{prec}> (z'=ST(z-A r), patches of B z', support map)":
+                (lambda: o.fused_iter(g, x, z, tau, frags, -1.0, patches, prec, out=out, map_out=bits), K,
+                 2 * fat + mapb + 2 * th),
             f"k_stage<BWD,{prec}> (du=[z'!=0](du'+B^T q), dtau, patches of A^T du)":
-                (lambda: o.fused_stage_bwd(g, x, gup, z, frags, patches, dtp, True, prec, out=out), K, 3 * fat + 2 * th),
+                (lambda: o.fused_stage_bwd(g, x, gup, bits, frags, patches, dtp, True, prec, out=out), K,
+                 2 * fat + mapb + 2 * th),
             f"k_wgrad2d<{prec}> (dA_k and dB_k)":
                 (lambda: o.fused_wgrad(g, ws, gup, x, -1.0, z, x, 1.0, prec), K, 2 * fat + 2 * th),
             "k_assemble (thin)": (lambda: o.fused_assemble(g, patches, None, x, 1.0, out=thin), 2 * K, 3 * th),

@@ -56,17 +56,17 @@ SIGNATURES = {
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_fused2d_supported": [_G],
     "cdl_fused2d_prep": [_P, _P, _P, _I, _I, _P],
-    "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
+    "cdl_fused2d_support_map": [_G, _P, _P, _P],
     "cdl_fused2d_assemble": [_G, _P, _P, _P, _F, _P, _P],
     "cdl_fused2d_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "cdl_fused2d_dtau_reduce": [_G, _P, _P, _P, _P, _P],
     "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
-    "cdl_fused2d_forward": [_G, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "cdl_fused2d_backward": [_G, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                             _P, _P, _I, _P],
+    "cdl_fused2d_forward": [_G, _I] + [_P] * 11 + [_I, _P],
+    "cdl_fused2d_backward": [_G, _I] + [_P] * 20 + [_I, _P],
 }
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
-                "cdl_fused2d_tiles": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
+                "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
                 "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G]}
 

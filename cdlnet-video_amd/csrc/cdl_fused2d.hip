@@ -59,7 +59,8 @@ constexpr int LDS_STAGE = LDS_RT + LDS_RSUM + LDS_W + LDS_TAU + LDS_TACC;
 struct FusedParams {
     const float *r;          // (N,H,W) thin input of the analysis-like half (r_k, yp, q_{k+1} or g_xp)
     const float *zin;        // (N,M,H,W) or nullptr: z_k (forward) / du_{k+1} (backward)
-    const float *gate;       // backward only: z_{k+1}, whose support gates the gradient
+    unsigned *map;           // support/sign bit planes of z_{k+1}, (N,4,H,W) words: written by the forward
+                             // (nullable), read by the backward instead of the fat z_{k+1} (see k_support_map)
     float *zout;             // (N,M,H,W): z_{k+1} (forward) / du_k (backward)
     const float *tau;        // forward: (N,M) thresholds
     float *dtau;             // backward: (numWG, M) per-workgroup partial sums of -sign(z_{k+1}) * du_k
@@ -272,7 +273,8 @@ __device__ __forceinline__ float col2im_row(const float (&rv)[4], int h)
 
 // ------------------------------------------------------------------------------------------
 // MODE_FWD / MODE_FIRST: zout = ST(zin + sgn * A r, tau)              (net.py:85,87)
-// MODE_BWD            : zout = [gate != 0] * (zin + A-like r),  dtau partials   (reverse sweep)
+// MODE_BWD            : zout = [z_{k+1} != 0] * (zin + A-like r),  dtau partials   (reverse sweep);
+//                       support and sign of z_{k+1} come from the 2-bit map, not from the fat tensor
 template <int MT, int PREC, int MODE, bool WIDE>
 __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 {
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
     const __amdgpu_buffer_rsrc_t rs_in = fat_rsrc(has_base ? p.zin + (size_t)n * img : p.zout, has_base ? img : 0);
-    const __amdgpu_buffer_rsrc_t rs_gate = fat_rsrc(MODE == MODE_BWD ? p.gate + (size_t)n * img : p.zout,
-                                                    MODE == MODE_BWD ? img : 0);
+    // bit 16R + v of the lane's words = register v of tile R: plane 2h holds [z != 0], plane 2h + 1 the sign bit
+    unsigned *const map_n = p.map ? p.map + ((size_t)n * 4 + 2 * h) * HW : nullptr;
     const __amdgpu_buffer_rsrc_t rs_out = fat_rsrc(p.zout + (size_t)n * img, img);
     const int lane_off = (int)((4 * h) * HW + x) * 4;
     const int p4 = c & 3;                                  // WIDE: channel 4h + p4, pixels 4(c>>2) .. +3
@@ -415,12 +417,12 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
-        float zc[MT][16], gc[MT][16];
+        float zc[MT][16];
         if (MODE != MODE_FIRST && (p.dbg & 16)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) { zc[R][v] = 0.25f; gc[R][v] = 1.0f; }
+                for (int v = 0; v < 16; ++v) zc[R][v] = 0.25f;
         } else if (MODE != MODE_FIRST && WIDE && !(p.dbg & 128)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
@@ -432,12 +434,6 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     quad_transpose(a, p4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) zc[R][4 * q4 + e] = a[e];
-                    if (MODE == MODE_BWD) {
-                        buf_ld4(a, rs_gate, voff_w, soff);
-                        quad_transpose(a, p4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) gc[R][4 * q4 + e] = a[e];
-                    }
                 }
         } else if (MODE != MODE_FIRST) {
 #pragma unroll
@@ -446,8 +442,12 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 for (int v = 0; v < 16; ++v) {
                     const int soff = (32 * R + 8 * (v >> 2) + (v & 3)) * hw4;
                     zc[R][v] = buf_ld(rs_in, voff, soff);
-                    if (MODE == MODE_BWD) gc[R][v] = buf_ld(rs_gate, voff, soff);
                 }
+        }
+        unsigned sup = 0, sgb = 0;           // backward: support / sign words of this lane's pixel (0 outside)
+        if (MODE == MODE_BWD && valid) {
+            sup = map_n[(size_t)y * p.W + x];
+            sgb = map_n[HW + (size_t)y * p.W + x];
         }
 
         // -- im2col fragments of the thin input: 8 consecutive rows yl..yl+7 of column xl + j
@@ -499,9 +499,9 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 const int chl = 32 * R + 8 * (v >> 2) + (v & 3);        // + 4h folded into lane_off
                 float zz;
                 if (MODE == MODE_BWD) {
-                    const float gt = gc[R][v];                          // 0 for out-of-image lanes
-                    zz = gt != 0.0f ? zc[R][v] + acc[R][v] : 0.0f;
-                    tsum[16 * R + v] += gt > 0.0f ? -zz : (gt < 0.0f ? zz : 0.0f);
+                    const bool on = (sup >> (16 * R + v)) & 1u;         // never for out-of-image lanes
+                    zz = on ? zc[R][v] + acc[R][v] : 0.0f;
+                    tsum[16 * R + v] += ((sgb >> (16 * R + v)) & 1u) ? zz : -zz;      // -sign(z') * du
                 } else {
                     const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
@@ -521,6 +521,21 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     quad_transpose(a, p4);
                     buf_st4(a, rs_out, voff_wst, (32 * R + 8 * q4) * hw4);
                 }
+        }
+        if (MODE != MODE_BWD && map_n) {      // training forward: 2 bits per code element for the reverse sweep
+            unsigned ws = 0, wg = 0;
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float zz = acc[R][v];
+                    ws |= (zz != 0.0f ? 1u : 0u) << (16 * R + v);
+                    wg |= (__builtin_bit_cast(unsigned, zz) >> 31) << (16 * R + v);
+                }
+            if (valid && !(p.dbg & 1)) {
+                map_n[(size_t)y * p.W + x] = ws;
+                map_n[HW + (size_t)y * p.W + x] = wg;
+            }
         }
         if (MODE == MODE_BWD && !p.do_synth) continue;
         if (p.dbg & 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
@@ -659,6 +674,32 @@ __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patc
     if (mask) sum *= mask[i];
     if (sub) sum -= sub[i];
     out[i] = sum;
+}
+
+// ------------------------------------------------------------------------------------------
+// Support / sign bit planes of a code tensor in the layout k_stage reads and writes them:
+// map[n][2h + s][y][x], s = 0: bit (16R + v) = [z[n][ch][y][x] != 0], s = 1: its sign bit, with
+// ch = 32R + 8(v>>2) + 4h + (v&3).  The training forward emits this map next to z_{k+1} (16 B per pixel
+// against 256 B for M = 64), so the reverse stage reads 2 bits per element instead of the fat tensor.
+// This kernel builds the same map from a tensor for callers that only hold z (tests, stepwise drivers).
+__global__ __launch_bounds__(256) void k_support_map(const float *__restrict__ z, unsigned *__restrict__ map,
+                                                     int N, int M, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * 2 * HW) return;
+    const size_t pix = i % HW;
+    const int h = (int)((i / HW) % 2), n = (int)(i / (2 * HW));
+    unsigned ws = 0, wg = 0;
+    for (int R = 0; R < M / 32; ++R)
+        for (int v = 0; v < 16; ++v) {
+            const int ch = 32 * R + 8 * (v >> 2) + 4 * h + (v & 3);
+            const float zz = z[((size_t)n * M + ch) * HW + pix];
+            ws |= (zz != 0.0f ? 1u : 0u) << (16 * R + v);
+            wg |= (__builtin_bit_cast(unsigned, zz) >> 31) << (16 * R + v);
+        }
+    map[((size_t)n * 4 + 2 * h) * HW + pix] = ws;
+    map[((size_t)n * 4 + 2 * h + 1) * HW + pix] = wg;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1071,9 +1112,25 @@ int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P
     return 0;
 }
 
+size_t cdl_fused2d_map_words(const cdl_geom *g)
+{
+    if (!fused_shape_ok(g)) return 0;
+    return (size_t)g->N * 4 * g->H * g->W;
+}
+
+int cdl_fused2d_support_map(const cdl_geom *g, const float *z, unsigned *map, void *stream)
+{
+    if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
+    if (!z || !map) return CDL_EINVAL;
+    const size_t total = (size_t)g->N * 2 * g->H * g->W;
+    k_support_map<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(z, map, g->N, g->M, g->H, g->W);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
 int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, const float *tau,
-                         const void *frags, float sgn, float *zout, float *patches, int precision,
-                         void *stream)
+                         const void *frags, float sgn, float *zout, float *patches, unsigned *map_out,
+                         int precision, void *stream)
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
@@ -1082,7 +1139,7 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     if (precision != 0 && precision != 1) return CDL_EINVAL;
     FusedParams p = {};
     p.rev = rev;
-    p.r = r; p.zin = zin; p.zout = zout; p.tau = tau;
+    p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = sgn; p.do_synth = 1; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
@@ -1090,19 +1147,19 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, precision, S(stream));
 }
 
-int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const float *gate,
+int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
                           const void *frags, float *du_out, float *patches, float *dtau_partial,
                           int do_synth, int precision, void *stream)
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
-    if (!thin || !gate || !frags || !du_out || !dtau_partial || du_out == base || du_out == gate) return CDL_EINVAL;
+    if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
     const int rev = (precision >> 4) & 1;
     precision &= ~CDL_TILES_REVERSED;
     if (precision != 0 && precision != 1) return CDL_EINVAL;
     FusedParams p = {};
     p.rev = rev;
-    p.r = thin; p.zin = base; p.gate = gate; p.zout = du_out; p.dtau = dtau_partial;
+    p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
@@ -1180,7 +1237,8 @@ static int snake_enabled()
 
 int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
                         const float *const *wA, const float *const *wB, float *const *z, float *const *r,
-                        float *xp, void *frags, float *patches, int precision, void *stream)
+                        unsigned *const *maps, float *xp, void *frags, float *patches, int precision,
+                        void *stream)
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
@@ -1191,7 +1249,8 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
         int rc = cdl_fused2d_prep(wA[k], wB[(k + 1) % K], frags, g->M, g->Ph, stream);
         if (rc) return rc;
         rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, frags, k ? -1.0f : 1.0f, z[k],
-                                  patches, precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+                                  patches, maps ? maps[k] : nullptr,
+                                  precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
         if (rc) return rc;
         if (k < K - 1) {
             rc = cdl_fused2d_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
@@ -1206,12 +1265,13 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
 
 int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *c,
                          const float *const *wA, const float *const *wB, const float *const *z,
-                         const float *const *r, const float *g_xp, const float *g_z, float *const *dA,
+                         const float *const *r, const unsigned *const *maps, const float *g_xp,
+                         const float *g_z, float *const *dA,
                          float *const *dB, float *dt, float *du0, float *du1, float *q, void *frags,
                          float *patches, float *dtau_partial, float *wgrad_ws, int precision, void *stream)
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
-    if (K < 1 || !yp || !wA || !wB || !z || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
+    if (K < 1 || !yp || !wA || !wB || !z || !maps || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
         !patches || !dtau_partial || !wgrad_ws || (K > 1 && !r))
         return CDL_EINVAL;
     const int M = g->M;
@@ -1228,7 +1288,7 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
         rc = cdl_fused2d_prep(wB[(k + 1) % K], wA[k], frags, M, g->Ph, stream);
         if (rc) return rc;
         float *duk = du[flip];
-        rc = cdl_fused2d_stage_bwd(g, thin, base, z[k], frags, duk, patches, dtau_partial, k >= 1, sprec, stream);
+        rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], frags, duk, patches, dtau_partial, k >= 1, sprec, stream);
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
         if (rc) return rc;

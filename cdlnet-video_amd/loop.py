@@ -43,7 +43,7 @@ def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     """Whole sweep from one C call (cdl_ista_forward): same launches as the stepwise form below."""
     keep = keep_codes or keep_resid
     xp, z, codes, resid, _ = ops.ista_forward(g, yp, mask_p, tau, A, B, keep)
-    return xp, z, codes, (resid if keep_resid else [])
+    return xp, z, codes, (resid if keep_resid else []), []
 
 
 def _forward_generic_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
@@ -60,15 +60,15 @@ def _forward_generic_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
         if keep_resid:
             resid.append(r)
     xp = ops.synthesis(g, z, B[0], 1.0)
-    return xp, z, codes, resid
+    return xp, z, codes, resid, []
 
 
 def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     """The whole sweep from one C call (cdl_fused2d_forward): per iteration one fused launch + a thin
     assemble, enqueued back to back with no per-launch host work."""
     keep = keep_codes or keep_resid
-    xp, z, codes, resid = ops.fused_forward(g, yp, mask_p, tau, A, B, keep, PRECISION)
-    return xp, z, codes, (resid if keep_resid else [])
+    xp, z, codes, resid, maps = ops.fused_forward(g, yp, mask_p, tau, A, B, keep, PRECISION)
+    return xp, z, codes, (resid if keep_resid else []), (maps if keep_resid else [])
 
 
 def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
@@ -76,28 +76,31 @@ def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     K = len(A)
     frags = [ops.fused_prep(A[k], B[(k + 1) % K]) for k in range(K)]   # last one pairs A_{K-1} with D = B_0
     patches = ops.fused_patches(g, yp.device)
-    codes, resid = [], []
+    codes, resid, maps = [], [], []
     r, z = yp, None
     for k in range(K):
-        z = ops.fused_iter(g, r, z, tau[k], frags[k], 1.0 if k == 0 else -1.0, patches, PRECISION)
+        bits = ops.fused_map(g, yp.device) if keep_resid else None
+        z = ops.fused_iter(g, r, z, tau[k], frags[k], 1.0 if k == 0 else -1.0, patches, PRECISION, map_out=bits)
         if keep_codes or k == 0:
             codes.append(z)
+        if keep_resid:
+            maps.append(bits)
         if k < K - 1:
             r = ops.fused_assemble(g, patches, mask_p, yp, 1.0)
             if keep_resid:
                 resid.append(r)
     xp = ops.fused_assemble(g, patches, None, None, 1.0)
-    return xp, z, codes, resid
+    return xp, z, codes, resid, maps
 
 
-def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
     """Reverse sweep from one C call (cdl_ista_backward)."""
     if g_xp is None and g_z is None:
         return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
     return ops.ista_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt)
 
 
-def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
     """Same reverse sweep driven launch by launch from Python (kept for tests and experiments)."""
     dA, dB = [None] * K, [None] * K
     zK = codes[K - 1]
@@ -119,14 +122,15 @@ def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_
     return dA, dB
 
 
-def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
-    """Reverse sweep from one C call (cdl_fused2d_backward): per iteration one stage launch (2 fat
-    reads, 1 fat write), a thin assemble, and one MFMA filter-gradient launch (2 fat reads)."""
+def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+    """Reverse sweep from one C call (cdl_fused2d_backward): per iteration one stage launch (1 fat read +
+    the 2-bit map of z_{k+1}, 1 fat write), a thin assemble, and one MFMA filter-gradient launch (2 fat
+    reads).  maps: the forward's bit maps (rebuilt from the codes when absent)."""
     return ops.fused_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
-                              PRECISION)
+                              PRECISION, maps=list(maps) if maps else None)
 
 
-def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt):
+def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
     """Same reverse sweep driven launch by launch from Python (kept for tests and experiments)."""
     prec = PRECISION
     dev = yp.device
@@ -138,7 +142,7 @@ def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z,
     (dB[0],) = ops.fused_wgrad(g, ws, codes[K - 1], g_xp, 1.0, precision=prec)[:1]
     for k in range(K - 1, -1, -1):
         frags = ops.fused_prep(B[(k + 1) % K], A[k])          # analysis-like bank, synthesis-like bank
-        du = ops.fused_stage_bwd(g, thin, du_next, codes[k], frags, patches, dtp, k >= 1, prec)
+        du = ops.fused_stage_bwd(g, thin, du_next, maps[k] if maps else codes[k], frags, patches, dtp, k >= 1, prec)
         ops.fused_dtau_reduce(g, dtp, c, dt[k])
         if k >= 1:
             q = ops.fused_assemble(g, patches, mask_p, None, -1.0)
@@ -171,7 +175,7 @@ class UnrolledISTA(torch.autograd.Function):
         want_codes = cfg.get("all_codes", False)
         ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
         sweep = _forward_fused if ctx.fused else _forward_generic
-        xp, z, codes, resid = sweep(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
+        xp, z, codes, resid, maps = sweep(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
         xhat = ops.postprocess(xp, mean, pads)
 
         ctx.geom, ctx.pads, ctx.K = g, pads, K
@@ -179,7 +183,8 @@ class UnrolledISTA(torch.autograd.Function):
         if keep:
             ctx.save_for_backward(yp, mask_p if mask_p is not None else yp.new_empty(0),
                                   c if c is not None else yp.new_empty(0), t, *weights,
-                                  *codes, *resid)
+                                  *codes, *resid, *maps)
+            ctx.n_maps = len(maps)
         outs = (xhat, z)
         if want_codes:
             extra = tuple(codes[:-1])
@@ -197,13 +202,15 @@ class UnrolledISTA(torch.autograd.Function):
         A = saved[4:4 + K]
         B = saved[4 + K:4 + 2 * K]
         codes = saved[4 + 2 * K:4 + 3 * K]            # z_1..z_K
-        resid = saved[4 + 3 * K:]                     # r_1..r_{K-1}
+        resid = saved[4 + 3 * K:4 + 3 * K + (K - 1)]  # r_1..r_{K-1}
+        maps = saved[4 + 3 * K + (K - 1):]            # fused path: support/sign bit maps of z_1..z_K
+        assert len(maps) == ctx.n_maps
         dt = torch.zeros((K, 2, g.M), device=yp.device, dtype=torch.float32)
         g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads) if g_xhat is not None else None
         if g_z is not None:
             g_z = g_z.contiguous()
         sweep = _backward_fused if (ctx.fused and g_xp is not None) else _backward_generic
-        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
+        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
 
         return (None, None, None, dt.reshape(t.shape), None, *dA, *dB)
 

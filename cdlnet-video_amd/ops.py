@@ -378,15 +378,36 @@ def fused_patches(g: Geometry, device):
     return torch.empty(n, device=device, dtype=torch.float32)
 
 
-def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3", out=None):
+def fused_map(g: Geometry, device):
+    """Empty support/sign bit map of one code tensor: (N, 4, H, W) int32 words (cdl_fused2d_map_words)."""
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_fused2d_map_words(ctypes.byref(gs)))
+    assert n == g.N * 4 * g.dims[1] * g.dims[2]
+    return torch.empty((g.N, 4, g.dims[1], g.dims[2]), device=device, dtype=torch.int32)
+
+
+def fused_support_map(g: Geometry, z, out=None):
+    """The bit map the reverse stage reads instead of the fat z (built from a tensor; the training forward
+    gets it for free from cdl_fused2d_iter_fwd)."""
+    z = _dev(z, "z")
+    assert tuple(z.shape) == g.code_shape()
+    if out is None:
+        out = fused_map(g, z.device)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fused2d_support_map(ctypes.byref(gs), _ptr(z), _ptr(out), _stream())
+    _lib.check(rc, "cdl_fused2d_support_map")
+    return out
+
+
+def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3", out=None, map_out=None):
     r, zin, tau = _dev(r, "r"), _opt(zin, "zin"), _dev(tau, "tau")
     assert tuple(r.shape) == g.image_shape()
     if out is None:
         out = torch.empty(g.code_shape(), device=r.device, dtype=torch.float32)
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_iter_fwd(ctypes.byref(gs), _ptr(r), _ptr(zin), _ptr(tau), _ptr(frags),
-                                         float(sgn), _ptr(out), _ptr(patches), PRECISION[precision],
-                                         _stream())
+                                         float(sgn), _ptr(out), _ptr(patches), _ptr(map_out),
+                                         PRECISION[precision], _stream())
     _lib.check(rc, "cdl_fused2d_iter_fwd")
     return out
 
@@ -410,8 +431,12 @@ def fused_tiles(g: Geometry) -> int:
 
 def fused_stage_bwd(g: Geometry, thin, base, gate, frags, patches, dtau_partial, do_synth,
                     precision="split3", out=None):
-    """One reverse-sweep stage: du = [gate != 0] * (base + corr(thin; W1)); patches = W2^T du."""
-    thin, base, gate = _dev(thin, "thin"), _opt(base, "base"), _dev(gate, "gate")
+    """One reverse-sweep stage: du = [z' != 0] * (base + corr(thin; W1)); patches = W2^T du.  `gate` is the
+    bit map of z' (int32, from the forward or fused_support_map) or z' itself (the map is built first)."""
+    thin, base = _dev(thin, "thin"), _opt(base, "base")
+    if gate.dtype != torch.int32:
+        gate = fused_support_map(g, gate)
+    assert gate.is_cuda and gate.is_contiguous() and gate.numel() == g.N * 4 * g.dims[1] * g.dims[2]
     if out is None:
         out = torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32)
     gs = g.c_struct()
@@ -465,8 +490,9 @@ def _ptr_table(tensors):
 
 
 def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
-    """Whole forward sweep in one C call.  keep=True: every z_k and r_k gets its own buffer (training);
-    keep=False: two ping-pong buffers each.  Returns (xp, z_K, codes, resid)."""
+    """Whole forward sweep in one C call.  keep=True: every z_k and r_k gets its own buffer (training) and
+    each launch also writes the support/sign bit map of its z_{k+1}; keep=False: two ping-pong buffers
+    each, no maps.  Returns (xp, z_K, codes, resid, maps)."""
     K = len(A)
     yp, tau = _dev(yp, "yp"), _dev(tau, "tau")
     mask_p = _opt(mask_p, "mask")
@@ -479,21 +505,26 @@ def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
     rbuf = [torch.empty(g.image_shape(), device=dev, dtype=torch.float32) for _ in range(nr)]
     z = [zbuf[k % nz] for k in range(K)]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
+    maps = [fused_map(g, dev) for _ in range(K)] if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
     frags = torch.empty(_lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
     patches = fused_patches(g, dev)
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
-                                        _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None, _ptr(xp),
-                                        _ptr(frags), _ptr(patches), PRECISION[precision], _stream())
+                                        _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None,
+                                        _ptr_table(maps) if maps else None, _ptr(xp), _ptr(frags), _ptr(patches),
+                                        PRECISION[precision], _stream())
     _lib.check(rc, "cdl_fused2d_forward")
-    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else [])
+    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else []), maps
 
 
-def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, precision="split3"):
-    """Whole reverse sweep in one C call; returns (dA list, dB list); dt (K,2,M) is written in place."""
+def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, precision="split3", maps=None):
+    """Whole reverse sweep in one C call; returns (dA list, dB list); dt (K,2,M) is written in place.
+    maps: the forward's bit maps of z_1..z_K (built here from the codes when not given)."""
     K = len(A)
     dev = yp.device
+    if not maps:
+        maps = [fused_support_map(g, t) for t in codes]
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
     codes = [_dev(t, "z") for t in codes]
@@ -512,7 +543,8 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_backward(
         ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(c), _ptr_table(A), _ptr_table(B), _ptr_table(codes),
-        _ptr_table(resid) if resid else None, _ptr(g_xp), _ptr(g_z), _ptr_table(dA), _ptr_table(dB), _ptr(dt),
+        _ptr_table(resid) if resid else None, _ptr_table(list(maps)), _ptr(g_xp), _ptr(g_z), _ptr_table(dA),
+        _ptr_table(dB), _ptr(dt),
         _ptr(du0), _ptr(du1), _ptr(q), _ptr(frags), _ptr(patches), _ptr(dtp), _ptr(ws), PRECISION[precision],
         _stream())
     _lib.check(rc, "cdl_fused2d_backward")

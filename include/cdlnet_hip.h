@@ -216,9 +216,17 @@ size_t cdl_fused2d_frag_bytes(int M);                      /* bytes of one prepa
 size_t cdl_fused2d_patch_floats(const cdl_geom *g);        /* floats in the patch workspace */
 /* fp32 filters (M,1,P,P) -> bf16 hi/lo MFMA operand fragments for one launch (A_k with B_next). */
 int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P, void *stream);
+/* map_out (nullable, cdl_fused2d_map_words(g) words): support / sign bit planes of z_{k+1} for the reverse
+ * sweep (2 bits per code element, written by the same launch). */
 int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/,
                          const float *tau /*N*M*/, const void *frags, float sgn, float *zout,
-                         float *patches, int precision, void *stream);
+                         float *patches, unsigned *map_out /*nullable*/, int precision, void *stream);
+/* The map of a code tensor, (N,4,H,W) 32-bit words: plane 2h holds [z != 0], plane 2h+1 the sign bit, bit
+ * 16R + v of a word = channel 32R + 8(v>>2) + 4h + (v&3) of that pixel (the MFMA accumulator layout).  The
+ * reverse stage reads it instead of the fat z_{k+1}: 16 B per pixel against 4*M.  cdl_fused2d_support_map
+ * builds it from a tensor for callers that did not get it from cdl_fused2d_iter_fwd. */
+size_t cdl_fused2d_map_words(const cdl_geom *g);
+int cdl_fused2d_support_map(const cdl_geom *g, const float *z, unsigned *map, void *stream);
 /* out = (mask ? mask : 1) * alpha * (sum of the overlapping patches) - (sub ? sub : 0) */
 int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *mask /*nullable*/,
                          const float *sub /*nullable*/, float alpha, float *out, void *stream);
@@ -227,14 +235,14 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
  * One stage per iteration k = K-1 .. 0, same kernel skeleton as the forward launch:
  *     g_{k+1} = base + corr(thin ; W1)          base = du_{k+1} (or dL/dz_K, nullable), thin = q_{k+1} (or
  *                                               dL/d(D z_K)), W1 = B_{k+1} (or B_0)
- *     du_k    = [gate != 0] * g_{k+1}           gate = z_{k+1}          -> du_out (fat, written once)
+ *     du_k    = [z_{k+1} != 0] * g_{k+1}        support and sign from `map` -> du_out (fat, written once)
  *     dtau    : per-workgroup partials of -sum sign(z_{k+1}) * du_k     -> dtau_partial (tiles x M)
  *     patches : partial W2^T du_k (W2 = A_k)    -> cdl_fused2d_assemble(alpha = -1, mask) gives q_k
  * frags = cdl_fused2d_prep(W1, W2).  do_synth = 0 for k = 0 (no q_0 is needed). */
 size_t cdl_fused2d_tiles(const cdl_geom *g);               /* workgroups (= dtau_partial rows) per launch */
 int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base /*nullable*/,
-                          const float *gate, const void *frags, float *du_out, float *patches,
-                          float *dtau_partial, int do_synth, int precision, void *stream);
+                          const unsigned *map /*of z_{k+1}*/, const void *frags, float *du_out,
+                          float *patches, float *dtau_partial, int do_synth, int precision, void *stream);
 /* dt0[m] = sum over workgroups; dt1[m] = sum_n c[n] * (sum over the workgroups of image n); c nullable */
 int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c /*N*/,
                             float *dt0 /*M*/, float *dt1 /*M*/, void *stream);
@@ -251,18 +259,20 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
 /* ---- whole sweeps in one call (same launches as above, enqueued from C: no per-launch host cost) ----
  * Pointer tables are HOST arrays of device pointers.  Forward: z[k] receives z_{k+1} (K entries; entries
  * may alias two ping-pong buffers when nothing is kept for training, as long as z[k] != z[k-1]); r[k]
- * receives r_{k+1} for k < K-1 (same aliasing rule); xp receives D z_K.  frags: cdl_fused2d_frag_bytes(M).
- * Backward (net.py forward lines in reverse): z[k] = z_{k+1}, r[k] = r_{k+1} as saved by the forward,
+ * receives r_{k+1} for k < K-1 (same aliasing rule); maps (nullable table) receives the bit map of z_{k+1};
+ * xp receives D z_K.  frags: cdl_fused2d_frag_bytes(M).
+ * Backward (net.py forward lines in reverse): z[k] = z_{k+1}, r[k] = r_{k+1}, maps[k] as saved by the forward,
  * g_xp = dL/d(D z_K), g_z = dL/dz_K or NULL; writes dA[k], dB[k] (filter shapes) and dt (K,2,M);
  * du0/du1 fat scratch, q thin scratch, dtau_partial (tiles x M), wgrad_ws (workspace_floats). */
 int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
                         const float *tau /*K,N,M*/, const float *const *wA, const float *const *wB,
-                        float *const *z, float *const *r, float *xp, void *frags, float *patches,
-                        int precision, void *stream);
+                        float *const *z, float *const *r, unsigned *const *maps /*nullable*/, float *xp,
+                        void *frags, float *patches, int precision, void *stream);
 int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
                          const float *c /*N, nullable*/, const float *const *wA, const float *const *wB,
-                         const float *const *z, const float *const *r, const float *g_xp,
-                         const float *g_z /*nullable*/, float *const *dA, float *const *dB, float *dt,
+                         const float *const *z, const float *const *r, const unsigned *const *maps,
+                         const float *g_xp, const float *g_z /*nullable*/, float *const *dA, float *const *dB,
+                         float *dt,
                          float *du0, float *du1, float *q, void *frags, float *patches,
                          float *dtau_partial, float *wgrad_ws, int precision, void *stream);
 

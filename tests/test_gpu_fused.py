@@ -88,7 +88,11 @@ def test_fused_iteration_vs_generic(N, M, P, H, W, masked, precision, tol):
         z_ref = o.analysis(geom, r, wA, sgn, zin, None, tau)
         r_ref = o.synthesis(geom, z_ref, wB, 1.0, None, mask, yp)
         patches.fill_(float("nan"))                       # every patch word that is read must be written
-        z_got = o.fused_iter(geom, r, zin, tau, frags, sgn, patches, precision)
+        bits = torch.full((N, 4, H, W), -1, dtype=torch.int32, device="cuda")     # every word must be written
+        z_got = o.fused_iter(geom, r, zin, tau, frags, sgn, patches, precision, map_out=bits)
+        assert torch.equal(bits, o.fused_support_map(geom, z_got)), f"{tag} {name}: support/sign map"
+        z_nomap = o.fused_iter(geom, r, zin, tau, frags, sgn, patches, precision)
+        assert torch.equal(z_nomap, z_got)
         r_got = o.fused_assemble(geom, patches, mask, yp)
         check(f"{tag} {name} z'", z_got, z_ref, tol)
         # the synthesis check feeds the fused kernel's own z' to the generic kernel: isolates the second GEMM
@@ -231,13 +235,13 @@ def test_fused_reverse_sweep_equals_generic_on_same_activations(K, M, P, shape, 
     tau = o.thresholds(net.t.detach(), c, N)
     A = [m.weight.detach() for m in net.A]
     B = [m.weight.detach() for m in net.B]
-    xp, z, codes, resid = loop._forward_fused(g, yp, mask_p, tau, A, B, True, True)
+    xp, z, codes, resid, maps = loop._forward_fused(g, yp, mask_p, tau, A, B, True, True)
     g_xp = torch.randn(xp.shape, generator=torch.Generator().manual_seed(8)).cuda()
     g_z = torch.randn(z.shape, generator=torch.Generator().manual_seed(9)).cuda() * 0.01
     outs = {}
     for name, sweep in (("fused", loop._backward_fused), ("generic", loop._backward_generic)):
         dt = torch.zeros(K, 2, M, device="cuda")
-        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
+        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
         outs[name] = (dA, dB, dt)
     tag = f"reverse sweep K{K} M{M} P{P} {shape}"
     for k in range(K):
@@ -319,18 +323,20 @@ def test_c_sweeps_are_bit_identical_to_stepwise_launches():
     tau = o.thresholds(net.t.detach(), c, N)
     A = [m.weight.detach() for m in net.A]
     B = [m.weight.detach() for m in net.B]
-    xp1, z1, codes1, resid1 = loop._forward_fused(g, yp, None, tau, A, B, True, True)
-    xp2, z2, codes2, resid2 = loop._forward_fused_stepwise(g, yp, None, tau, A, B, True, True)
+    xp1, z1, codes1, resid1, maps1 = loop._forward_fused(g, yp, None, tau, A, B, True, True)
+    xp2, z2, codes2, resid2, maps2 = loop._forward_fused_stepwise(g, yp, None, tau, A, B, True, True)
+    assert len(maps1) == K and all(torch.equal(a, b) for a, b in zip(maps1, maps2))
+    assert all(torch.equal(m, o.fused_support_map(g, zc)) for m, zc in zip(maps1, codes1))   # forward map == builder
     assert torch.equal(xp1, xp2) and torch.equal(z1, z2)
     assert all(torch.equal(a, b) for a, b in zip(codes1, codes2)) and len(codes1) == K
     assert all(torch.equal(a, b) for a, b in zip(resid1, resid2)) and len(resid1) == K - 1
-    xp3, z3, codes3, resid3 = loop._forward_fused(g, yp, None, tau, A, B, False, False)     # ping-pong buffers
-    assert torch.equal(xp3, xp1) and torch.equal(z3, z1) and len(codes3) == 1 and resid3 == []
+    xp3, z3, codes3, resid3, maps3 = loop._forward_fused(g, yp, None, tau, A, B, False, False)     # ping-pong buffers
+    assert torch.equal(xp3, xp1) and torch.equal(z3, z1) and len(codes3) == 1 and resid3 == [] and maps3 == []
     g_xp = torch.randn(xp1.shape, generator=torch.Generator().manual_seed(2)).cuda()
     outs = []
     for sweep in (loop._backward_fused, loop._backward_fused_stepwise):
         dt = torch.zeros(K, 2, M, device="cuda")
-        dA, dB = sweep(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt)
+        dA, dB = sweep(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt, maps=maps1)
         outs.append((dA, dB, dt))
     for k in range(K):
         check(f"snake dA[{k}]", outs[0][0][k], outs[1][0][k], 2e-6)
@@ -339,7 +345,7 @@ def test_c_sweeps_are_bit_identical_to_stepwise_launches():
     again = []
     for _ in range(2):                                # the sweep itself is reproducible bit for bit
         dt = torch.zeros(K, 2, M, device="cuda")
-        again.append(loop._backward_fused(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt) + (dt,))
+        again.append(loop._backward_fused(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt) + (dt,))   # maps rebuilt
     for k in range(K):
         assert torch.equal(again[0][0][k], again[1][0][k]) and torch.equal(again[0][1][k], again[1][1][k])
     assert torch.equal(again[0][2], again[1][2])

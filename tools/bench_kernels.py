@@ -37,10 +37,15 @@ def main():
     frags = o.fused_prep(w, w)
     patches = o.fused_patches(g, dev)
     rows = []
+    bits = o.fused_support_map(g, z)
+    mapb = bits.numel() * 4
     for prec in ("split3", "bf16"):
         ms = ev(lambda: o.fused_iter(g, r, z, tau, frags, -1.0, patches, prec, out=out))
         rows.append({"kernel": f"k_iter_fwd[{prec}]", "ms": ms, "alg_bytes": 2 * fat + 2 * th,
                      "GBps": (2 * fat + 2 * th) / ms / 1e6, "Mpix_iter_per_s": N * S * S / ms / 1e3})
+    ms = ev(lambda: o.fused_iter(g, r, z, tau, frags, -1.0, patches, "split3", out=out, map_out=bits))
+    rows.append({"kernel": "k_iter_fwd[split3,+map]", "ms": ms, "alg_bytes": 2 * fat + mapb + 2 * th,
+                 "GBps": (2 * fat + mapb + 2 * th) / ms / 1e6})
     ms = ev(lambda: o.fused_iter(g, r, None, tau, frags, 1.0, patches, "split3", out=out))
     rows.append({"kernel": "k_iter_fwd[split3,first]", "ms": ms, "alg_bytes": fat + 2 * th,
                  "GBps": (fat + 2 * th) / ms / 1e6})
@@ -48,9 +53,9 @@ def main():
     dtp = torch.empty((o.fused_tiles(g), M), device=dev)
     ws = o.fused_wgrad_workspace(g, dev)
     for prec in ("split3", "bf16"):
-        ms = ev(lambda: o.fused_stage_bwd(g, r, gup, z, frags, patches, dtp, True, prec, out=out))
-        rows.append({"kernel": f"k_stage<BWD>[{prec}]", "ms": ms, "alg_bytes": 3 * fat + 2 * th,
-                     "GBps": (3 * fat + 2 * th) / ms / 1e6})
+        ms = ev(lambda: o.fused_stage_bwd(g, r, gup, bits, frags, patches, dtp, True, prec, out=out))
+        rows.append({"kernel": f"k_stage<BWD>[{prec}]", "ms": ms, "alg_bytes": 2 * fat + mapb + 2 * th,
+                     "GBps": (2 * fat + mapb + 2 * th) / ms / 1e6})
         ms = ev(lambda: o.fused_wgrad(g, ws, gup, r, -1.0, z, r, 1.0, prec))
         rows.append({"kernel": f"k_wgrad2d[{prec}]", "ms": ms, "alg_bytes": 2 * fat + 2 * th,
                      "GBps": (2 * fat + 2 * th) / ms / 1e6})
