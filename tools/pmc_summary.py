@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) over
+tools/bench_kernels.py into profiles/<tag>_pmc_traffic.json: HBM bytes per launch of every fused kernel.
+
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+
+Counter values are in KiB.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half
+of the bytes of coalesced streaming reads); the same pass calibrates that on __amd_rocclr_copyBuffer.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+MODES = {0: "FWD", 1: "FIRST", 2: "BWD"}
+PRECS = {0: "split3", 1: "bf16"}
+
+
+def label(name):
+    m = re.search(r"k_stage<(\d+), (\d+), (\d+)(, (false|true))?>", name)       # <MT, PREC, MODE[, WIDE]>
+    if m:
+        if m.group(5) == "true":
+            return None
+        return f"k_stage<{MODES[int(m.group(3))]},{PRECS[int(m.group(2))]}>"
+    m = re.search(r"k_wgrad2d<(\d+), (\d+)(, (false|true))?>", name)
+    if m:
+        return None if m.group(4) == "true" else f"k_wgrad2d<{PRECS[int(m.group(2))]}>"
+    for k in ("k_assemble", "k_support_map", "__amd_rocclr_copyBuffer"):
+        if k in name:
+            return k
+    return None
+
+
+def fold(path, counter):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        lab = label(row["Kernel_Name"])
+        if lab:
+            acc[lab].append(float(row["Counter_Value"]) * 1024.0)
+    return {k: sorted(v)[len(v) // 2] for k, v in acc.items()}          # median launch
+
+
+def main():
+    fetch, write = fold(sys.argv[1], "FETCH_SIZE"), fold(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        kernels[k] = {"fetch_reported": int(f), "fetch_corrected": int(2 * f), "write": int(w),
+                      "traffic": int(2 * f + w)}
+    out = {"_note": __doc__.strip().split("\n\n")[-1].replace("\n", " ") +
+           " Median launch per kernel; k_stage<FWD,split3> mixes launches with and without the support map"
+           " (67 MB more written with it).",
+           "shape": {"N": 64, "M": 64, "H": 256, "W": 256, "P": 7}, "kernels": kernels}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(kernels, indent=1))
+
+
+if __name__ == "__main__":
+    main()
