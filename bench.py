@@ -11,6 +11,7 @@ all-reduce (N>1) -> clip -> Adam -> project -- on a synthetic 64 x 1 x 256 x 256
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -200,7 +201,9 @@ def main():
     loop.set_precision(args.precision)
     K, M, P, B, S = args.K, args.M, args.P, args.batch, args.size
     torch.manual_seed(1)
-    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    # the constructor prints its power-method log like the reference's; stdout carries the JSON line only
+    with contextlib.redirect_stdout(sys.stderr):
+        net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
     sd_cpu = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net = net.to(dev)
     broadcast_parameters(net)

@@ -92,11 +92,10 @@ __device__ __forceinline__ float embed7(const float *w, int P, int i, int j)
     return w[ii * P + jj];
 }
 
-__global__ void k_prep(const float *__restrict__ wA, const float *__restrict__ wB,
-                       uint4 *__restrict__ out, int MT, int P)
+__device__ __forceinline__ void prep_one(const float *__restrict__ wA, const float *__restrict__ wB,
+                                         uint4 *__restrict__ out, int MT, int P, int t)
 {
     const int FA = MT * 4, FB = 4 * MT;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (FA + FB) * 64) return;
     const int lane = t & 63, f = t >> 6;
     const int row = lane & 31, h = lane >> 5;
@@ -130,6 +129,24 @@ __global__ void k_prep(const float *__restrict__ wA, const float *__restrict__ w
     else { hi_dst = out + (size_t)(2 * FA + (f - FA)) * 64; lo_dst = out + (size_t)(2 * FA + FB + (f - FA)) * 64; }
     hi_dst[lane] = __builtin_bit_cast(uint4, hi);
     lo_dst[lane] = __builtin_bit_cast(uint4, lo);
+}
+
+__global__ void k_prep(const float *__restrict__ wA, const float *__restrict__ wB,
+                       uint4 *__restrict__ out, int MT, int P)
+{
+    prep_one(wA, wB, out, MT, P, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every (A, B) pair of a sweep in one launch: pair = blockIdx.y, its fragments at out + pair * frag_uint4
+constexpr int PREP_BATCH = 32;
+struct PrepBatch {
+    const float *wA[PREP_BATCH];
+    const float *wB[PREP_BATCH];
+};
+__global__ void k_prep_batch(PrepBatch b, uint4 *__restrict__ out, int frag_uint4, int MT, int P)
+{
+    prep_one(b.wA[blockIdx.y], b.wB[blockIdx.y], out + (size_t)blockIdx.y * frag_uint4, MT, P,
+             blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Fat tensors are addressed through buffer descriptors: the descriptor covers one image's (M,H,W)
@@ -634,29 +651,36 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
 // ------------------------------------------------------------------------------------------
 // out[n,Y,X] = (mask ? mask : 1) * alpha * sum_{patches covering (Y,X)} patch - (sub ? sub : 0)
-// The covering patches are visited in (tile row, tile column) order: a fixed summation order.  A pixel
-// at least HALO away from its tile's border is covered by its own patch only (the common case).
+// A pixel is covered by its own tile's patch and, within HALO of a tile border, by the neighbour's across
+// that border (and the diagonal one in a corner): at most 4 patches, visited in (tile row, tile column) order.
 __device__ __forceinline__ float patch_sum(const float *__restrict__ patches, int n, int Y, int X,
                                            int tilesX, int tilesY)
 {
     const int tyc = Y / TH, txc = X / TW;
     const int ly = Y - tyc * TH, lx = X - txc * TW;
-    const float *own = patches + (((size_t)n * tilesY + tyc) * tilesX + txc) * SLAB;
-    if (ly >= HALO && ly < TH - HALO && lx >= HALO && lx < TW - HALO) return own[(ly + HALO) * RTW + lx + HALO];
+    const int hx = (lx < HALO && txc > 0) ? -1 : ((lx >= TW - HALO && txc + 1 < tilesX) ? 1 : 0);
+    const int vy = (ly < HALO && tyc > 0) ? -1 : ((ly >= TH - HALO && tyc + 1 < tilesY) ? 1 : 0);
+    const float *own = patches + (((size_t)n * tilesY + tyc) * tilesX + txc) * SLAB + (ly + HALO) * RTW + lx + HALO;
+    const ptrdiff_t dx = (ptrdiff_t)hx * (SLAB - TW), dy = (ptrdiff_t)vy * ((ptrdiff_t)tilesX * SLAB - TH * RTW);
+    // the same pixel in the neighbour's patch: one tile over (SLAB words) and TW columns / TH rows back
     float sum = 0.0f;
-    for (int ty = tyc - 1; ty <= tyc + 1; ++ty) {
-        if (ty < 0 || ty >= tilesY) continue;
-        const int yy = Y - (ty * TH - HALO);
-        if (yy < 0 || yy >= RTH) continue;
-        for (int tx = txc - 1; tx <= txc + 1; ++tx) {
-            if (tx < 0 || tx >= tilesX) continue;
-            const int xx = X - (tx * TW - HALO);
-            if (xx < 0 || xx >= RTW) continue;
-            sum += patches[(((size_t)n * tilesY + ty) * tilesX + tx) * SLAB + yy * RTW + xx];
-        }
+    if (vy < 0) {
+        if (hx < 0) sum += own[dy + dx];
+        sum += own[dy];
+        if (hx > 0) sum += own[dy + dx];
+    }
+    if (hx < 0) sum += own[dx];
+    sum += own[0];
+    if (hx > 0) sum += own[dx];
+    if (vy > 0) {
+        if (hx < 0) sum += own[dy + dx];
+        sum += own[dy];
+        if (hx > 0) sum += own[dy + dx];
     }
     return sum;
 }
+
+constexpr int ASM_ROWS = 4;      // image rows per thread: fewer, fatter workgroups and 4 independent load chains
 
 __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patches,
                                                   const float *__restrict__ mask,
@@ -664,16 +688,19 @@ __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patc
                                                   float *__restrict__ out, int N, int H, int W,
                                                   int tilesX, int tilesY)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)N * H * W;
-    if (i >= total) return;
-    const int X = i % W;
-    const size_t r = i / W;
-    const int Y = r % H, n = r / H;
-    float sum = alpha * patch_sum(patches, n, Y, X, tilesX, tilesY);
-    if (mask) sum *= mask[i];
-    if (sub) sum -= sub[i];
-    out[i] = sum;
+    // grid (ceil(W/256), ceil(H/ASM_ROWS), N): no runtime divisions (TW, TH are powers of two), rows coalesced
+    const int X = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z;
+    if (X >= W) return;
+#pragma unroll
+    for (int j = 0; j < ASM_ROWS; ++j) {
+        const int Y = blockIdx.y * ASM_ROWS + j;
+        if (Y >= H) break;
+        const size_t i = ((size_t)n * H + Y) * W + X;
+        float sum = alpha * patch_sum(patches, n, Y, X, tilesX, tilesY);
+        if (mask) sum *= mask[i];
+        if (sub) sum -= sub[i];
+        out[i] = sum;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1217,9 +1244,8 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
-    const size_t total = (size_t)g->N * g->H * g->W;
-    k_assemble<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(
-        patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
+    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + ASM_ROWS - 1) / ASM_ROWS), (unsigned)g->N);
+    k_assemble<<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1229,6 +1255,29 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
  * the bytes the previous one touched last, which are still in the 256 MiB Infinity Cache (it holds
  * the last ~256 MiB loaded or stored).  Tile results do not depend on the order; only the filter
  * gradients' per-workgroup partial sums are grouped differently.  CDL_FUSED_SNAKE=0 turns it off. */
+// fragments of K (analysis-like, synthesis-like) pairs, pair k at frags + k * cdl_fused2d_frag_bytes(M)
+static int prep_pairs(const float *const *w1, const float *const *w2, int K, int shift2, void *frags, int M, int P,
+                      hipStream_t st)
+{
+    const int MT = M / 32, threads = 8 * MT * 64;
+    const int frag_uint4 = (int)(cdl_fused2d_frag_bytes(M) / 16);
+    for (int k0 = 0; k0 < K; k0 += PREP_BATCH) {
+        const int nb = K - k0 < PREP_BATCH ? K - k0 : PREP_BATCH;
+        PrepBatch b = {};
+        for (int i = 0; i < nb; ++i) {
+            const int k = k0 + i;
+            // forward: (A_k, B_{k+1 mod K});  backward: (B_{k+1 mod K}, A_k) -- the shifted bank is index shift2
+            b.wA[i] = shift2 == 0 ? w1[(k + 1) % K] : w1[k];
+            b.wB[i] = shift2 == 0 ? w2[k] : w2[(k + 1) % K];
+        }
+        dim3 grid((unsigned)((threads + 255) / 256), (unsigned)nb);
+        k_prep_batch<<<grid, 256, 0, st>>>(b, reinterpret_cast<uint4 *>(frags) + (size_t)k0 * frag_uint4, frag_uint4, MT, P);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
+
 static int snake_enabled()
 {
     static const int on = [] { const char *e = getenv("CDL_FUSED_SNAKE"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1245,10 +1294,12 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
     const size_t nm = (size_t)g->N * g->M;
     const int snake = snake_enabled();
     const float *thin = yp;
+    const size_t fb = cdl_fused2d_frag_bytes(g->M);
+    int rc = prep_pairs(wA, wB, K, 1, frags, g->M, g->Ph, S(stream));       // (A_k, B_{k+1}) for every k, one launch
+    if (rc) return rc;
     for (int k = 0; k < K; ++k) {
-        int rc = cdl_fused2d_prep(wA[k], wB[(k + 1) % K], frags, g->M, g->Ph, stream);
-        if (rc) return rc;
-        rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, frags, k ? -1.0f : 1.0f, z[k],
+        const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
+        rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k],
                                   patches, maps ? maps[k] : nullptr,
                                   precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
         if (rc) return rc;
@@ -1284,11 +1335,13 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
                                wprec, stream);                           // dB_0 = z_K (x) dL/d(D z_K)
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
+    const size_t fb = cdl_fused2d_frag_bytes(M);
+    rc = prep_pairs(wB, wA, K, 0, frags, M, g->Ph, S(stream));               // (B_{k+1}, A_k) for every k, one launch
+    if (rc) return rc;
     for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
-        rc = cdl_fused2d_prep(wB[(k + 1) % K], wA[k], frags, M, g->Ph, stream);
-        if (rc) return rc;
+        const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         float *duk = du[flip];
-        rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], frags, duk, patches, dtau_partial, k >= 1, sprec, stream);
+        rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1, sprec, stream);
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
         if (rc) return rc;

@@ -507,7 +507,7 @@ def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
     maps = [fused_map(g, dev) for _ in range(K)] if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
-    frags = torch.empty(_lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
+    frags = torch.empty(K * _lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
     patches = fused_patches(g, dev)
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
@@ -535,7 +535,7 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
     du0 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
     du1 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32) if K > 1 else du0
     q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
-    frags = torch.empty(_lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
+    frags = torch.empty(K * _lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
     patches = fused_patches(g, dev)
     dtp = torch.empty((fused_tiles(g), g.M), device=dev, dtype=torch.float32)
     ws = fused_wgrad_workspace(g, dev)

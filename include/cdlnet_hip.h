@@ -260,7 +260,7 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
  * Pointer tables are HOST arrays of device pointers.  Forward: z[k] receives z_{k+1} (K entries; entries
  * may alias two ping-pong buffers when nothing is kept for training, as long as z[k] != z[k-1]); r[k]
  * receives r_{k+1} for k < K-1 (same aliasing rule); maps (nullable table) receives the bit map of z_{k+1};
- * xp receives D z_K.  frags: cdl_fused2d_frag_bytes(M).
+ * xp receives D z_K.  frags: K * cdl_fused2d_frag_bytes(M) bytes (every pair is prepared up front, one launch).
  * Backward (net.py forward lines in reverse): z[k] = z_{k+1}, r[k] = r_{k+1}, maps[k] as saved by the forward,
  * g_xp = dL/d(D z_K), g_z = dL/dz_K or NULL; writes dA[k], dB[k] (filter shapes) and dt (K,2,M);
  * du0/du1 fat scratch, q thin scratch, dtau_partial (tiles x M), wgrad_ws (workspace_floats). */
