@@ -3,9 +3,14 @@
 `init_model` mirrors the reference's factory (train.py:180-219, train3d.py:174-206,
 traincsr.py:281-302) so an `args.json` builds the same net + Adam + StepLR; `train_step` is the
 body of the reference's batch loop (train.py:76-103 / train3d.py:90-118) with the data-parallel
-gradient exchange added (parallel.py).  Data loading, checkpoint rotation, backtracking and
-plotting are outside the hot path and are not re-implemented here.
+gradient exchange added (parallel.py); `fit` is the reference's epoch driver (train.py:35-158: phases,
+PSNR logs, divergence backtracking with learning-rate decay, checkpoint rotation, MC-SURE option) around
+that step.  Data loading and plotting are outside the hot path and are not re-implemented here.
 """
+import json
+import os
+
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -69,9 +74,23 @@ def init_model(args, device=torch.device("cpu")):
     return net, opt, sched, epoch0
 
 
+def mcsure_loss(net, obsrv, xhat, sigma, mask=1, h=1e-3, generator=None, b=None):
+    """Monte-Carlo SURE objective of train.py:87-93: data fidelity to the OBSERVATION plus a divergence
+    estimate from one extra forward at obsrv + h*b, b ~ N(0, I):
+        mean((obsrv - xhat)^2) + 2 * mean((sigma/255)^2 * b * (net(obsrv + h b) - xhat)) / h
+    Gradients flow through both forward passes (both run in the HIP kernels)."""
+    if b is None:
+        b = torch.randn(obsrv.shape, device=obsrv.device, dtype=obsrv.dtype, generator=generator)
+    xhat_b, _ = net(obsrv.clone() + h * b, sigma, mask=mask)
+    s2 = (sigma / 255.0) ** 2
+    div = 2.0 * torch.mean(s2 * b * (xhat_b - xhat)) / h
+    return torch.mean((obsrv - xhat) ** 2) + div
+
+
 def train_step(net, opt, batch, noise_std, clip_grad=None, demosaic=False, project=True,
-               grad_sync=None, generator=None):
-    """One optimiser step: awgn -> forward -> MSE -> backward -> [all-reduce] -> clip -> Adam -> project.
+               grad_sync=None, generator=None, mcsure=False):
+    """One optimiser step: awgn -> forward -> MSE (or MC-SURE) -> backward -> [all-reduce] -> clip -> Adam
+    -> project (train.py:76-102).
 
     `grad_sync` is a callable run between backward and clipping (parallel.GradientBucket.sync).
     Returns (loss tensor, sigma).
@@ -81,7 +100,10 @@ def train_step(net, opt, batch, noise_std, clip_grad=None, demosaic=False, proje
     obsrv = mask * noisy
     opt.zero_grad(set_to_none=True)
     xhat, _ = net(obsrv, sigma, mask=mask)
-    loss = torch.mean((batch - xhat) ** 2)
+    if mcsure:
+        loss = mcsure_loss(net, obsrv, xhat, sigma, mask=mask, generator=generator)
+    else:
+        loss = torch.mean((batch - xhat) ** 2)
     loss.backward()
     if grad_sync is not None:
         grad_sync()
@@ -91,3 +113,123 @@ def train_step(net, opt, batch, noise_std, clip_grad=None, demosaic=False, proje
     if project and hasattr(net, "project"):
         net.project()
     return loss.detach(), sigma
+
+
+# ------------------------------------------------------------------------------------------ fit loop
+def grad_norm(params):
+    """l2 norm of the mini-batch gradient (train.py:161-170)."""
+    total = 0.0
+    for p in params:
+        if p.grad is not None:
+            total += float(p.grad.detach().norm(2)) ** 2
+    return total ** 0.5
+
+
+def getlr(opt):
+    return [pg["lr"] for pg in opt.param_groups]
+
+
+def setlr(opt, lr):
+    if not isinstance(lr, (list, tuple, np.ndarray)):
+        lr = [lr for _ in opt.param_groups]
+    for pg, v in zip(opt.param_groups, lr):
+        pg["lr"] = float(v)
+
+
+def save_args(args, ckpt=True):
+    """train.py:249-258: args.json next to the checkpoints, pointing `paths.ckpt` at net.ckpt."""
+    save_path = args["paths"]["save"]
+    if ckpt:
+        args["paths"]["ckpt"] = os.path.join(save_path, "net.ckpt")
+    with open(os.path.join(save_path, "args.json"), "w") as f:
+        f.write(json.dumps(args, indent=4, sort_keys=True))
+
+
+def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), save_dir=None, start_epoch=1,
+        clip_grad=1, noise_std=25, demosaic=False, verbose=True, val_freq=1, save_freq=1, epoch_fun=None,
+        mcsure=False, backtrack_thresh=1, grad_sync=None, log=print):
+    """The reference's training driver (train.py:35-158), same arguments and files:
+
+    * phases train / val (every `val_freq` epochs) / test (only at `epoch == epochs`, as written there);
+      val and test use the mid-range noise level;
+    * per-epoch PSNR = mean over batches of -10 log10(loss), appended to `{phase}.txt`;
+    * divergence backtracking: when a phase's PSNR falls `backtrack_thresh` dB below its best, or the loss
+      is nan/inf, reload `net.ckpt` (`0.ckpt` while `epoch <= save_freq`), scale every learning rate by 0.8,
+      rewind `epoch` to the checkpointed one and log it in `backtrack.txt`;
+    * scheduler step per epoch; `net.ckpt` (+ `epoch_fun(epoch)`) every `save_freq` epochs; `0.ckpt` at start.
+
+    `loaders` maps phase -> iterable of clean batches.  `grad_sync` (new) is run after backward for data
+    parallel training (parallel.GradientBucket.sync); every rank then needs its own `save_dir` (or a
+    shared one written by identical ranks) so that backtracking reloads the same weights everywhere.
+    Returns the history [(epoch, phase, psnr)].
+    """
+    if save_dir is None:
+        raise ValueError("fit needs save_dir (checkpoints drive the backtracking)")
+    os.makedirs(save_dir, exist_ok=True)
+    if not isinstance(noise_std, (list, tuple)):
+        noise_std = (noise_std, noise_std)
+    log(f"fit: using device {device}")
+    log("Saving initialization to 0.ckpt")
+    save_ckpt(os.path.join(save_dir, "0.ckpt"), net, 0, opt, sched)
+    top_psnr = {"train": 0, "val": 0, "test": 0}
+    history = []
+    epoch = start_epoch
+    while epoch < start_epoch + epochs:
+        diverged, loss = False, 0.0
+        for phase in ("train", "val", "test"):
+            net.train() if phase == "train" else net.eval()
+            if epoch != epochs and phase == "test":
+                continue
+            if phase == "val" and epoch % val_freq != 0:
+                continue
+            if phase not in loaders or loaders[phase] is None:
+                continue
+            phase_nstd = noise_std if phase == "train" else (noise_std[0] + noise_std[1]) / 2.0
+            psnr, nb = 0.0, 0
+            for batch in loaders[phase]:
+                batch = batch.to(device)
+                if phase == "train":
+                    loss_t, _ = train_step(net, opt, batch, phase_nstd, clip_grad=clip_grad, demosaic=demosaic,
+                                           grad_sync=grad_sync, mcsure=mcsure)
+                else:
+                    with torch.no_grad():
+                        mask = gen_bayer_mask(batch) if demosaic else 1
+                        noisy, sigma = awgn(batch, phase_nstd)
+                        xhat, _ = net(mask * noisy, sigma, mask=mask)
+                        loss_t = torch.mean((batch - xhat) ** 2)
+                loss = float(loss_t)
+                if verbose and phase == "train":
+                    log(f"{phase.upper()}-E{epoch} loss={loss:.1e}|gnorm={grad_norm(net.parameters()):.1e}")
+                psnr = psnr - 10 * np.log10(loss) if loss > 0 else float("nan")
+                nb += 1
+            psnr = psnr / max(nb, 1)
+            log(f"{phase.upper()} PSNR: {psnr:.3f} dB")
+            history.append((epoch, phase, psnr))
+            if psnr > top_psnr[phase]:
+                top_psnr[phase] = psnr
+            elif (psnr + backtrack_thresh < top_psnr[phase]) or np.isnan(loss) or np.isinf(loss) or np.isnan(psnr):
+                diverged = True
+                break
+            with open(os.path.join(save_dir, f"{phase}.txt"), "a") as f:
+                f.write(f"{psnr:.3f}, ")
+        if diverged:
+            ckpt_path = os.path.join(save_dir, "0.ckpt" if epoch <= save_freq else "net.ckpt")
+            log(f"Loss has diverged. Backtracking to {ckpt_path} ...")
+            with open(os.path.join(save_dir, "backtrack.txt"), "a") as f:
+                f.write(f"{epoch}  ")
+            epoch = epoch - save_freq if epoch % save_freq == 0 else epoch - epoch % save_freq
+            old_lr = np.array(getlr(opt))
+            load_ckpt(ckpt_path, net, opt, sched)
+            net.to(device)
+            setlr(opt, old_lr * 0.8)
+            log(f"Updated Learning Rate(s): {getlr(opt)}")
+            epoch = epoch + 1
+            continue
+        if sched is not None:
+            sched.step()
+        if epoch % save_freq == 0:
+            save_ckpt(os.path.join(save_dir, "net.ckpt"), net, epoch, opt, sched)
+            if epoch_fun is not None:
+                epoch_fun(epoch)
+        epoch = epoch + 1
+    return history

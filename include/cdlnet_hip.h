@@ -151,6 +151,15 @@ int cdl_prox_csr_bwd(const cdl_geom *g, const float *gz, const float *u, const f
                      size_t scratch_floats, void *stream);
 size_t cdl_prox_csr_scratch_floats(const cdl_geom *g);
 
+/* ---- blind noise-level estimate --------------------------------------
+ * model/nle.py:17-27 (nle_mad) with the filter of model/wvlt.py:13-41: sigma_hat[n] = median over (C,H',W') of
+ * |conv2d(y, flip(outer(dec_hi, dec_hi)) of 'bior4.4', stride 2, groups C)| / 0.6745, the lower median as
+ * torch.median returns it (exact selection, no sort).  y (N,C,H,W) in the reference's [0,1] scale, H,W >= 10;
+ * callers multiply by 255 (analyze.py:139).  scratch: cdl_nle_mad_scratch_floats(N,C,H,W) floats. */
+size_t cdl_nle_mad_scratch_floats(int N, int C, int H, int W);
+int cdl_nle_mad(const float *y, float *sigma_hat /*N*/, float *scratch, size_t scratch_floats, int N, int C,
+                int H, int W, void *stream);
+
 /* ---- whole sweeps of the shape-generic loop in one call ------------------------------------------
  * The same launches as K x (cdl_synthesis_ws, cdl_analysis | cdl_analysis_prox) + the final synthesis,
  * resp. the reverse sweep (cdl_tau_grad | cdl_prox_csr_bwd, cdl_synthesis_ws, 2 x cdl_wgrad, cdl_analysis

@@ -25,6 +25,8 @@ Reference lines restated (all relative to /root/reference):
   awgn / bayer_mask     utils.py:13-55
   train_step            train.py:76-102, train3d.py:90-116
   psnr                  analyze.py:104, analyze3d.py:131-133
+  hh_filter / nle_mad   model/wvlt.py:13-41, model/nle.py:17-27 (taps restated: PyWavelets is not installed)
+  mcsure_loss_and_grads train.py:87-93 (restated from the text; the reference has it inline in fit())
   prox_csr / prox_csr_f2  model/net.py:229-262
   ista_csr              model/net.py:426-463 (CDLNet_CSR.forward), 525-568 (CDLNet_CSRf2.forward)
 """
@@ -171,6 +173,39 @@ def ista(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, ndim=2, gab
     xp = synthesis(codes[-1], B[0], s, pad)          # D is B[0] (net.py:34)
     xhat = postprocess(xp, mean, pads)
     return (xhat, codes) if all_codes else (xhat, codes[-1])
+
+
+# --------------------------------------------------------------------------- blind noise level (MAD)
+# PyWavelets' 'bior4.4' filter bank (pywt.Wavelet('bior4.4').filter_bank: dec_lo, dec_hi, rec_lo, rec_hi),
+# restated from the published CDF 9/7 pair because pywt is not installed here ("parity unpinned" against
+# the library itself; tests pin the table through the perfect-reconstruction identity).
+BIOR44 = {
+    "dec_lo": [0.0, 0.03782845550726404, -0.023849465019556843, -0.11062440441843718, 0.37740285561283066,
+               0.8526986790088938, 0.37740285561283066, -0.11062440441843718, -0.023849465019556843,
+               0.03782845550726404],
+    "dec_hi": [0.0, -0.06453888262869706, 0.04068941760916406, 0.41809227322161724, -0.7884856164055829,
+               0.41809227322161724, 0.04068941760916406, -0.06453888262869706, 0.0, 0.0],
+    "rec_lo": [0.0, -0.06453888262869706, -0.04068941760916406, 0.41809227322161724, 0.7884856164055829,
+               0.41809227322161724, -0.04068941760916406, -0.06453888262869706, 0.0, 0.0],
+    "rec_hi": [0.0, -0.03782845550726404, -0.023849465019556843, 0.11062440441843718, 0.37740285561283066,
+               -0.8526986790088938, 0.37740285561283066, 0.11062440441843718, -0.023849465019556843,
+               -0.03782845550726404],
+}
+
+
+def hh_filter():
+    """model/wvlt.py:13-41 reduced to the one band nle_mad takes: filter_bank_2D('bior4.4')[0][3:4], i.e.
+    outer(dec_hi, dec_hi) flipped along both axes (`nonsep` flips so that conv2d's correlation convolves)."""
+    hi = torch.tensor(BIOR44["dec_hi"], dtype=torch.float32)
+    return torch.outer(hi, hi).flip(0, 1)[None, None]
+
+
+def nle_mad(y):
+    """model/nle.py:17-27."""
+    C = y.shape[1]
+    hh = torch.cat([hh_filter()] * C)
+    band = F.conv2d(y, hh, stride=2, groups=C)
+    return (torch.median(band.abs().reshape(y.shape[0], -1), dim=1)[0] / 0.6745).reshape(-1, 1, 1, 1)
 
 
 # --------------------------------------------------------------------------- CSR temporal variants
@@ -397,6 +432,22 @@ def loss_and_grads(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, gab
     loss.backward()
     grads = {k: (leaves[k].grad if leaves[k].grad is not None else None) for k in keys}
     return float(loss.detach()), grads, xhat.detach()
+
+
+def mcsure_loss_and_grads(sd, obsrv, b, *, K, P, s, sigma, adaptive, mask=None, ndim=2, h=1e-3):
+    """The unsupervised objective of train.py:87-93 (one extra forward at obsrv + h*b) and its gradients:
+    mean((obsrv - xhat)^2) + 2 * mean((sigma/255)^2 * b * (xhat_b - xhat)) / h."""
+    keys = trainable(sd, K, False)
+    work = dict(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work.update(leaves)
+    kw = dict(K=K, P=P, s=s, sigma=sigma, adaptive=adaptive, mask=mask, ndim=ndim)
+    xhat, _ = ista(work, obsrv, **kw)
+    xhat_b, _ = ista(work, obsrv.clone() + h * b, **kw)
+    div = 2.0 * torch.mean(((sigma / 255.0) ** 2) * b * (xhat_b - xhat)) / h
+    loss = torch.mean((obsrv - xhat) ** 2) + div
+    loss.backward()
+    return float(loss.detach()), {k: leaves[k].grad for k in keys}
 
 
 def train_step(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, lr=1e-3, clip=None,

@@ -199,3 +199,23 @@ def test_properties_at_full_cfg1_batch():
     assert torch.isfinite(xhat).all()
     assert abs(float(xhat.mean() - y.mean())) < 5e-3
     assert O.psnr(x, xhat.cpu()) > O.psnr(x, y)
+
+
+def test_mcsure_objective_vs_oracle():
+    """train.py:87-93: two forward passes share the parameters; loss and every gradient against autograd
+    of the oracle with the same probe b.  (The reference has this inline in fit(): restated, not a fixture.)"""
+    import cdlnet_video_amd as cva
+    g, net, sigma, mask = run_case("f2_2d_s2_odd", "2d")
+    K, M, P, s, C = hyper(g)
+    y = g["y"]
+    b = torch.randn(y.shape, generator=torch.Generator().manual_seed(12))
+    ref_loss, ref_grads = O.mcsure_loss_and_grads(g["sd"], y, b, K=K, P=P, s=s, sigma=g["sigma"], adaptive=True)
+    yd = y.cuda()
+    xhat, _ = net(yd, sigma)
+    loss = cva.mcsure_loss(net, yd, xhat, sigma, b=b.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+    for pname, p in net.named_parameters():
+        if pname != "g":
+            # the divergence term is a difference of two forwards divided by h = 1e-3: fp32 noise is amplified 1000x
+            check(f"mcsure grad {pname}", p.grad, ref_grads[pname], 1e-3)
