@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcdlnet_hip.so")
+# CDLNET_HIP_LIB points at an alternative build of the same library (kernel experiments); default in-tree
+LIB_PATH = os.environ.get("CDLNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libcdlnet_hip.so")
 
 CDL_EINVAL = -10001
 CDL_EUNSUPPORTED = -10002

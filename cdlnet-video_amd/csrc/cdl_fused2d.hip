@@ -153,17 +153,24 @@ __global__ void k_prep_batch(PrepBatch b, uint4 *__restrict__ out, int frag_uint
 // block, the per-lane part of the address is ONE 32-bit VGPR byte offset shared by every channel of
 // the block and the channel stride goes in an SGPR -- no 64-bit per-access address registers, and an
 // out-of-image lane simply carries an out-of-range offset (loads return 0, stores are dropped).
+// cache-policy bits of the fat buffer accesses (0 = default; 2 = nt, streaming): build-time experiment knobs
+#ifndef CDL_FAT_LD_AUX
+#define CDL_FAT_LD_AUX 0
+#endif
+#ifndef CDL_FAT_ST_AUX
+#define CDL_FAT_ST_AUX 0
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fat_rsrc(const float *base, size_t img_floats)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(img_floats * 4), 0x00020000);
 }
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, CDL_FAT_LD_AUX));
 }
 __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, CDL_FAT_ST_AUX);
 }
 constexpr int OOB = 0x7fff0000;              // byte offset beyond any descriptor range
 
