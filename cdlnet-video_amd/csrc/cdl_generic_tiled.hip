@@ -292,14 +292,17 @@ __global__ __launch_bounds__(256) void k_wgrad_t(cdl_geom g, const float *__rest
 // filter gradient, second tier: one workgroup per (m, c, kd) and per chunk of code rows, all
 // PH x PW taps of the filter plane in registers, so the code is read C*Pd times in total instead
 // of C*Pd*Ph times.  Partial sums per row chunk go to `part`; k_wgrad_fold adds them in order.
+constexpr int ZR = 2;             // code rows per thread in k_wgrad_p: their image-row windows overlap
+
 template <int PH, int PW, int SW>
 __global__ __launch_bounds__(256) void k_wgrad_p(cdl_geom g, const float *__restrict__ z,
                                                  const float *__restrict__ gate,
                                                  const float *__restrict__ x, float *__restrict__ part,
-                                                 int rows_per_chunk)
+                                                 int groups_per_chunk, int lpr_shift)
 {
     __shared__ float red[4][PH * PW];
     constexpr int WL = (PXT - 1) * SW + PW;
+    constexpr int NXR = (ZR - 1) * SW + PH;               // image rows under ZR consecutive code rows
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
     const int m = blockIdx.x;
     const int kd = blockIdx.y % g.Pd, c = blockIdx.y / g.Pd;
@@ -309,44 +312,58 @@ __global__ __launch_bounds__(256) void k_wgrad_p(cdl_geom g, const float *__rest
 #pragma unroll
         for (int j = 0; j < PW; ++j) acc[i][j] = 0.0f;
 
-    const int W4 = (Wz + PXT - 1) / PXT;
-    const int rows = g.N * Dz * Hz;
-    const int r0 = blockIdx.z * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-    const long items = (long)(r1 - r0) * W4;
-    for (long it = threadIdx.x; it < items; it += 256) {
-        const int row = r0 + (int)(it / W4), zx0 = (int)(it % W4) * PXT;
-        const int zy = row % Hz, t = row / Hz;
+    // work item = (group of ZR code rows of one (n, zd) plane, quad of 4 code columns); a power-of-two
+    // number of lanes walks the quads of a row group, the other lanes take further row groups:
+    // 32-bit index arithmetic only, one division per row group
+    const int W4 = (Wz + PXT - 1) / PXT, HG = (Hz + ZR - 1) / ZR;
+    const int groups = g.N * Dz * HG;
+    const int g0 = blockIdx.z * groups_per_chunk, g1 = min(groups, g0 + groups_per_chunk);
+    const int lpr = 1 << lpr_shift, q0 = threadIdx.x & (lpr - 1), gstep = 256 >> lpr_shift;
+    for (int grp = g0 + (threadIdx.x >> lpr_shift); grp < g1; grp += gstep) {
+        const int zyg = grp % HG, t = grp / HG;
         const int zd = t % Dz, n = t / Dz;
         const int d = zd * g.sd - g.pd + kd;
         if (d < 0 || d >= g.D) continue;
-        const size_t zoff = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy) * Wz + zx0;
-        float zv[PXT];
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < PXT; ++p) {
-            float v = (zx0 + p < Wz) ? z[zoff + p] : 0.0f;
-            if (gate && v != 0.0f && gate[zoff + p] == 0.0f) v = 0.0f;
-            zv[p] = v;
-            any |= v != 0.0f;
-        }
-        if (!any) continue;
+        const int zy0 = zyg * ZR, yb = zy0 * g.sh - g.ph;
         const float *xplane = x + (((size_t)n * g.C + c) * g.D + d) * g.H * g.W;
-        const int xb = zx0 * SW - g.pw, yb = zy * g.sh - g.ph;
+        const size_t zrow0 = ((((size_t)n * g.M + m) * Dz + zd) * Hz + zy0) * Wz;
+        for (int q = q0; q < W4; q += lpr) {
+            const int zx0 = q * PXT;
+            float zv[ZR][PXT];
+            bool any = false;
 #pragma unroll
-        for (int ki = 0; ki < PH; ++ki) {
-            const int y = yb + ki;
-            if (y < 0 || y >= g.H) continue;
-            const float *xr = xplane + (size_t)y * g.W;
-            float win[WL];
+            for (int r = 0; r < ZR; ++r)
 #pragma unroll
-            for (int i = 0; i < WL; ++i) {
-                const int xx = xb + i;
-                win[i] = (xx >= 0 && xx < g.W) ? xr[xx] : 0.0f;
+                for (int p = 0; p < PXT; ++p) {
+                    const size_t zi = zrow0 + (size_t)r * Wz + zx0 + p;
+                    float v = (zy0 + r < Hz && zx0 + p < Wz) ? z[zi] : 0.0f;
+                    if (gate && v != 0.0f && gate[zi] == 0.0f) v = 0.0f;
+                    zv[r][p] = v;
+                    any |= v != 0.0f;
+                }
+            if (!any) continue;
+            const int xb = zx0 * SW - g.pw;
+#pragma unroll
+            for (int xr = 0; xr < NXR; ++xr) {
+                const int y = yb + xr;
+                if (y < 0 || y >= g.H) continue;
+                const float *xrow = xplane + (size_t)y * g.W;
+                float win[WL];
+#pragma unroll
+                for (int i = 0; i < WL; ++i) {
+                    const int xx = xb + i;
+                    win[i] = (xx >= 0 && xx < g.W) ? xrow[xx] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < ZR; ++r) {
+                    const int ki = xr - r * SW;                        // compile-time after unrolling
+                    if (ki < 0 || ki >= PH) continue;
+#pragma unroll
+                    for (int kj = 0; kj < PW; ++kj)
+#pragma unroll
+                        for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[r][p], win[p * SW + kj], acc[ki][kj]);
+                }
             }
-#pragma unroll
-            for (int kj = 0; kj < PW; ++kj)
-#pragma unroll
-                for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[p], win[p * SW + kj], acc[ki][kj]);
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -501,18 +518,21 @@ int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const 
     if (workspace) {
         // second tier: whole filter planes in registers, code rows split into chunks
         const int total = g->M * g->C * g->Pd * g->Ph * g->Pw;
-        const int rows = g->N * (g->D / g->sd) * (g->H / g->sh);
+        const int Hz = g->H / g->sh, Wz = g->W / g->sw;
+        const int rows = g->N * (g->D / g->sd) * ((Hz + ZR - 1) / ZR);      // row groups of ZR code rows
         int chunks = 2048 / (g->M * g->C * g->Pd);
         if (chunks < 1) chunks = 1;
         if (chunks > rows) chunks = rows;
         while (chunks > 1 && (size_t)chunks * total > workspace_floats) --chunks;
         const int rpc = (rows + chunks - 1) / chunks;
         chunks = (rows + rpc - 1) / rpc;
+        int lpr_shift = 0;                                                   // lanes per row group: pow2 >= quads
+        while ((1 << lpr_shift) < (Wz + PXT - 1) / PXT && lpr_shift < 8) ++lpr_shift;
         if ((size_t)chunks * total <= workspace_floats) {
             dim3 grid2((unsigned)g->M, (unsigned)(g->C * g->Pd), (unsigned)chunks);
 #define CDL_P(PH_, PW_, SW_)                                                                              \
             if (g->Ph == PH_ && g->Pw == PW_ && g->sw == SW_) {                                            \
-                k_wgrad_p<PH_, PW_, SW_><<<grid2, 256, 0, S(stream)>>>(*g, z, gate, x, workspace, rpc);    \
+                k_wgrad_p<PH_, PW_, SW_><<<grid2, 256, 0, S(stream)>>>(*g, z, gate, x, workspace, rpc, lpr_shift); \
                 CDL_LAUNCH_CHECK();                                                                        \
                 k_wgrad_fold<<<(total + 255) / 256, 256, 0, S(stream)>>>(workspace, dw, alpha, chunks, total); \
                 CDL_LAUNCH_CHECK();                                                                        \
