@@ -687,8 +687,9 @@ __device__ __forceinline__ float patch_sum(const float *__restrict__ patches, in
     return sum;
 }
 
-constexpr int ASM_ROWS = 4;      // image rows per thread: fewer, fatter workgroups and 4 independent load chains
-
+// ASM_ROWS image rows per thread: 4 for batches (fewer, fatter workgroups, 4 independent load chains), 1 for
+// single small images where the launch is latency-bound and wants every workgroup it can get
+template <int ASM_ROWS>
 __global__ __launch_bounds__(256) void k_assemble(const float *__restrict__ patches,
                                                   const float *__restrict__ mask,
                                                   const float *__restrict__ sub, float alpha,
@@ -1251,8 +1252,13 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
-    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + ASM_ROWS - 1) / ASM_ROWS), (unsigned)g->N);
-    k_assemble<<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
+    if ((size_t)g->N * g->H * g->W >= ((size_t)1 << 20)) {
+        dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)g->N);
+        k_assemble<4><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
+    } else {
+        dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)g->N);
+        k_assemble<1><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
+    }
     CDL_LAUNCH_CHECK();
     return 0;
 }

@@ -501,11 +501,12 @@ def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
     dev = yp.device
     nz = K if keep else min(K, 2)
     nr = (K - 1) if keep else min(K - 1, 2)
-    zbuf = [torch.empty(g.code_shape(), device=dev, dtype=torch.float32) for _ in range(nz)]
-    rbuf = [torch.empty(g.image_shape(), device=dev, dtype=torch.float32) for _ in range(nr)]
+    # one allocation per family (K views into it): at cfg1's size the allocator calls cost more than the kernels
+    zbuf = torch.empty((nz,) + g.code_shape(), device=dev, dtype=torch.float32)
+    rbuf = torch.empty((max(nr, 1),) + g.image_shape(), device=dev, dtype=torch.float32)
     z = [zbuf[k % nz] for k in range(K)]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
-    maps = [fused_map(g, dev) for _ in range(K)] if keep else []
+    maps = list(torch.empty((K, g.N, 4, g.dims[1], g.dims[2]), device=dev, dtype=torch.int32).unbind(0)) if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
     frags = torch.empty(K * _lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
     patches = fused_patches(g, dev)
@@ -530,8 +531,8 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
     codes = [_dev(t, "z") for t in codes]
     resid = [_dev(t, "r") for t in resid]
     g_xp, g_z, c, mask_p = _dev(g_xp, "g_xp"), _opt(g_z, "g_z"), _opt(c, "c"), _opt(mask_p, "mask")
-    dA = [torch.empty_like(w) for w in A]
-    dB = [torch.empty_like(w) for w in B]
+    dAB = torch.empty((2 * K,) + g.filter_shape(), device=dev, dtype=torch.float32)     # one allocation, 2K views
+    dA, dB = list(dAB[:K].unbind(0)), list(dAB[K:].unbind(0))
     du0 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
     du1 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32) if K > 1 else du0
     q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
@@ -575,11 +576,11 @@ def ista_forward(g: Geometry, yp, mask_p, tau, A, B, keep, z_prev=None, z_after=
     dev = yp.device
     nz = K if keep else min(K, 2)
     nr = (K - 1) if keep else min(K - 1, 2)
-    zbuf = [_new(g.code_shape(), dev) for _ in range(nz)]
-    rbuf = [_new(g.image_shape(), dev) for _ in range(nr)]
+    zbuf = _new((nz,) + g.code_shape(), dev)
+    rbuf = _new((max(nr, 1),) + g.image_shape(), dev)
     z = [zbuf[k % nz] for k in range(K)]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
-    u = [_new(g.code_shape(), dev) for _ in range(K)] if (keep and z_prev is not None) else []
+    u = list(_new((K,) + g.code_shape(), dev).unbind(0)) if (keep and z_prev is not None) else []
     xp = _new(g.image_shape(), dev)
     ws, n = ista_scratch(g, dev)
     gs = g.c_struct()
@@ -598,8 +599,8 @@ def ista_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt,
     dev = yp.device
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
-    dA = [_new(g.filter_shape(), dev) for _ in range(K)]
-    dB = [_new(g.filter_shape(), dev) for _ in range(K)]
+    dAB = _new((2 * K,) + g.filter_shape(), dev)
+    dA, dB = list(dAB[:K].unbind(0)), list(dAB[K:].unbind(0))
     g0, g1, q = _new(g.code_shape(), dev), _new(g.code_shape(), dev), _new(g.image_shape(), dev)
     ws, n = ista_scratch(g, dev)
     gs = g.c_struct()

@@ -98,7 +98,8 @@ def run(name):
     rel = float((xhat[:ncpu] - xr).abs().max() / xr.abs().max())
     from cdlnet_video_amd import loop, ops
     out = {"config": name, "model": f"{cls.__name__} {kw}", "input": list(shape),
-           "fused_path": bool(kind == "2d" and kw["C"] == 1 and kw["s"] == 1 and kw["M"] in (32, 64)),
+           "fused_path": bool(kind in ("2d", "gabor") and kw["C"] == 1 and kw["s"] == 1 and kw["M"] in (32, 64)
+                              and kw["P"] <= 7),
            "fwd_ms": round(f_ms, 3), "fwd_mpix_s": round(pix / f_ms / 1e3, 3),
            "fwdbwd_ms": round(fb_ms, 3), "fwdbwd_mpix_s": round(pix / fb_ms / 1e3, 3),
            "cpu_fwd_mpix_s": round(cpix / cf / 1e6, 4), "cpu_fwdbwd_mpix_s": round(cpix / cfb / 1e6, 4),
