@@ -609,7 +609,11 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
     if (!cdl_geom_ok(g)) return 0;
     const size_t total = (size_t)g->M * g->C * g->Pd * g->Ph * g->Pw;
     size_t chunks = 2048 / ((size_t)g->M * g->C * g->Pd);
-    return total * (chunks < 1 ? 1 : chunks);
+    const size_t by_rows = total * (chunks < 1 ? 1 : chunks);                    // k_wgrad_p
+    // k_wgrad_l: one partial filter bank per 64 x 32 tile of code pixels (cdl_generic_tiled.hip)
+    const size_t tiles = (size_t)g->N * (g->D / g->sd) * ((g->W / g->sw + 63) / 64) * ((g->H / g->sh + 31) / 32);
+    const size_t by_tiles = tiles <= 4096 ? tiles * total : 0;                   // <= a few tens of MB
+    return by_rows > by_tiles ? by_rows : by_tiles;
 }
 
 int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,

@@ -384,6 +384,136 @@ __global__ __launch_bounds__(256) void k_wgrad_p(cdl_geom g, const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// filter gradient, image tile in LDS: a workgroup owns a 64 x 32 tile of code pixels of one (n, zd) and one
+// (c, kd); the image rows under it (thin) are staged in LDS ONCE and every code channel m is then taken by
+// one of the 4 waves in turn: z is read exactly C*Pd times in total (k_wgrad_p re-fetches the image windows
+// from L1/L2 for every m: M x more image traffic and 3 FMAs per global load).  A lane accumulates its
+// PH x PW plane over 4 items of 2 code rows x 4 columns, the wave reduces it by a butterfly and writes the
+// per-(tile, c, kd, m) partial; k_wgrad_tfold adds the tiles in a fixed order.
+constexpr int WLX = 64, WLY = 32;     // code-pixel tile of k_wgrad_l
+
+template <int PH, int PW, int SW>
+__global__ __launch_bounds__(256) void k_wgrad_l(cdl_geom g, const float *__restrict__ z,
+                                                 const float *__restrict__ gate,
+                                                 const float *__restrict__ x, float *__restrict__ part,
+                                                 int tilesX, int tilesY, int XW)
+{
+    extern __shared__ float xt[];                          // [XH][XW] image rows under the tile (zero outside)
+    constexpr int WL = (PXT - 1) * SW + PW;
+    constexpr int NXR = (ZR - 1) * SW + PH;
+    constexpr int XH = (WLY - 1) * SW + PH;
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b % Dz, n = b / Dz;
+    const int kd = blockIdx.y % g.Pd, c = blockIdx.y / g.Pd;
+    const int d = zd * g.sd - g.pd + kd;
+    const bool dok = d >= 0 && d < g.D;                    // uniform: a plane outside the image contributes zeros
+    const int ybase = ty * WLY * SW - g.ph, xbase = tx * WLX * SW - g.pw;
+    if (dok) {
+        const float *xplane = x + (((size_t)n * g.C + c) * g.D + d) * g.H * g.W;
+        for (int i = threadIdx.x; i < XH * XW; i += 256) {
+            const int col = i % XW, row = i / XW;
+            const int yy = ybase + row, xx = xbase + col;
+            xt[i] = (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t pbase = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * g.M;      // [tile][c,kd][m][PH*PW]
+    for (int m = wv; m < g.M; m += 4) {
+        float acc[PH][PW];
+#pragma unroll
+        for (int i = 0; i < PH; ++i)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) acc[i][j] = 0.0f;
+        if (dok) {
+            const size_t zplane = (((size_t)n * g.M + m) * Dz + zd) * Hz;
+#pragma unroll 1
+            for (int it = 0; it < (WLX / PXT) * (WLY / ZR) / 64; ++it) {
+                const int item = lane + 64 * it;
+                const int q = item & (WLX / PXT - 1), rp = item / (WLX / PXT);
+                const int zy0 = ty * WLY + rp * ZR, zx0 = tx * WLX + q * PXT;
+                float zv[ZR][PXT];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < ZR; ++r)
+#pragma unroll
+                    for (int p = 0; p < PXT; ++p) {
+                        const size_t zi = (zplane + zy0 + r) * Wz + zx0 + p;
+                        float v = (zy0 + r < Hz && zx0 + p < Wz) ? z[zi] : 0.0f;
+                        if (gate && v != 0.0f && gate[zi] == 0.0f) v = 0.0f;
+                        zv[r][p] = v;
+                        any |= v != 0.0f;
+                    }
+                if (!any) continue;
+                const float *xrow = xt + (rp * ZR * SW) * XW + q * PXT * SW;
+#pragma unroll
+                for (int xr = 0; xr < NXR; ++xr) {
+                    // 16-byte LDS reads (XW and the column offset are multiples of 4 words): with 4-byte reads
+                    // every lane's address is 0 mod 4 words and a wave uses 8 of the 32 banks
+                    constexpr int WL4 = (WL + 3) / 4;
+                    float win[WL4 * 4];
+                    const float4 *x4 = reinterpret_cast<const float4 *>(xrow + xr * XW);
+#pragma unroll
+                    for (int i = 0; i < WL4; ++i) {
+                        const float4 v4 = x4[i];
+                        win[4 * i] = v4.x; win[4 * i + 1] = v4.y; win[4 * i + 2] = v4.z; win[4 * i + 3] = v4.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < ZR; ++r) {
+                        const int ki = xr - r * SW;                    // compile-time after unrolling
+                        if (ki < 0 || ki >= PH) continue;
+#pragma unroll
+                        for (int kj = 0; kj < PW; ++kj)
+#pragma unroll
+                            for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[r][p], win[p * SW + kj], acc[ki][kj]);
+                    }
+                }
+            }
+        }
+        // butterfly over the 64 lanes (fixed order), then lanes 0..PH*PW-1 store one tap each
+        float *dst = part + (pbase + m) * (PH * PW);
+#pragma unroll
+        for (int i = 0; i < PH; ++i)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                float v = acc[i][j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == ((i * PW + j) & 63)) dst[i * PW + j] = v;
+            }
+    }
+}
+
+// dw[m][c][kd][tap] = alpha * sum_tiles part[tile][c,kd][m][tap].  16 outputs x 16 tile-strided partial sums
+// per workgroup, combined through LDS in a fixed order (serial per-output loops over ~500 tiles cost 0.2 ms).
+__global__ __launch_bounds__(256) void k_wgrad_tfold(const float *__restrict__ part, float *__restrict__ dw,
+                                                     float alpha, int tiles, int CPd, int M, int taps)
+{
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, ps = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o, total = M * CPd * taps;
+    float s = 0.0f;
+    if (i < total) {
+        const int tap = i % taps;
+        const int r = i / taps;
+        const int cy = r % CPd, m = r / CPd;
+        const size_t off = ((size_t)cy * M + m) * taps + tap, tstride = (size_t)CPd * M * taps;
+        for (int t = ps; t < tiles; t += 16) s += part[(size_t)t * tstride + off];
+    }
+    red[ps][o] = s;
+    __syncthreads();
+    if (ps == 0 && i < total) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][o];
+        dw[i] = alpha * v;                                  // dw layout (M, C, Pd, Ph, Pw) = [m][cy][tap]
+    }
+}
+
 __global__ void k_wgrad_fold(const float *__restrict__ part, float *__restrict__ dw, float alpha, int chunks,
                              int total)
 {
@@ -526,6 +656,29 @@ int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const 
 {
     if (g->sw != g->sh) return CDL_EUNSUPPORTED;
     if (workspace) {
+        // first choice: image tile in LDS, every code channel inside the workgroup (z read C*Pd times in total)
+        const int Dz_ = g->D / g->sd, Hz_ = g->H / g->sh, Wz_ = g->W / g->sw;
+        const int tX = (Wz_ + WLX - 1) / WLX, tY = (Hz_ + WLY - 1) / WLY;
+        const long tiles = (long)g->N * Dz_ * tX * tY;
+        const int CPd = g->C * g->Pd, tapsl = g->Ph * g->Pw;
+        const int XW = (((WLX - 1) * g->sw + g->Pw + 3) + 3) & ~3;     // multiple of 4 words + room for the 16-byte reads
+        const size_t ldsl = (size_t)((WLY - 1) * g->sh + g->Ph) * XW * sizeof(float);
+        if (tiles * CPd >= 128 && (size_t)tiles * CPd * g->M * tapsl <= workspace_floats && ldsl <= 64 * 1024 &&
+            tiles < (1L << 31)) {
+            dim3 gridl((unsigned)tiles, (unsigned)CPd);
+            const int totall = g->M * CPd * tapsl;
+#define CDL_L(PH_, PW_, SW_)                                                                              \
+            if (g->Ph == PH_ && g->Pw == PW_ && g->sw == SW_) {                                            \
+                k_wgrad_l<PH_, PW_, SW_><<<gridl, 256, ldsl, S(stream)>>>(*g, z, gate, x, workspace, tX, tY, XW); \
+                CDL_LAUNCH_CHECK();                                                                        \
+                k_wgrad_tfold<<<(totall + 15) / 16, 256, 0, S(stream)>>>(workspace, dw, alpha, (int)tiles, CPd, g->M, tapsl); \
+                CDL_LAUNCH_CHECK();                                                                        \
+                return 0;                                                                                  \
+            }
+            CDL_L(3, 3, 1) CDL_L(5, 5, 1) CDL_L(7, 7, 1) CDL_L(9, 9, 1) CDL_L(3, 5, 1) CDL_L(7, 5, 1) CDL_L(9, 5, 1)
+            CDL_L(3, 3, 2) CDL_L(5, 5, 2) CDL_L(7, 7, 2) CDL_L(9, 9, 2) CDL_L(3, 5, 2) CDL_L(7, 5, 2) CDL_L(9, 5, 2)
+#undef CDL_L
+        }
         // second tier: whole filter planes in registers, code rows split into chunks
         const int total = g->M * g->C * g->Pd * g->Ph * g->Pw;
         const int Hz = g->H / g->sh, Wz = g->W / g->sw;
