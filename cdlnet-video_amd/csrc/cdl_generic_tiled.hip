@@ -423,57 +423,76 @@ __global__ __launch_bounds__(256) void k_wgrad_l(cdl_geom g, const float *__rest
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t pbase = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * g.M;      // [tile][c,kd][m][PH*PW]
+    constexpr int NIT = (WLX / PXT) * (WLY / ZR) / 64;    // items (2 code rows x 4 columns) per lane and channel
+    // the code values of ALL items of a channel are loaded up front, and the next channel's while this one
+    // is multiplied: with one item's loads at a time the kernel sat on global-load latency (15 % of VALU peak)
+    auto load_items = [&](int m, float (&dst)[NIT][ZR][PXT]) {
+        const size_t zplane = (((size_t)n * g.M + m) * Dz + zd) * Hz;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = lane + 64 * it;
+            const int q = item & (WLX / PXT - 1), rp = item / (WLX / PXT);
+            const int zy0 = ty * WLY + rp * ZR, zx0 = tx * WLX + q * PXT;
+#pragma unroll
+            for (int r = 0; r < ZR; ++r)
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) {
+                    const bool ok = dok && zy0 + r < Hz && zx0 + p < Wz;
+                    const size_t zi = ok ? (zplane + zy0 + r) * Wz + zx0 + p : 0;
+                    float v = z[zi];
+                    if (gate && gate[zi] == 0.0f) v = 0.0f;
+                    dst[it][r][p] = ok ? v : 0.0f;
+                }
+        }
+    };
+    float zv[NIT][ZR][PXT], zn[NIT][ZR][PXT];
+    if (wv < g.M) load_items(wv, zv);
     for (int m = wv; m < g.M; m += 4) {
+        if (m + 4 < g.M) load_items(m + 4, zn);
         float acc[PH][PW];
 #pragma unroll
         for (int i = 0; i < PH; ++i)
 #pragma unroll
             for (int j = 0; j < PW; ++j) acc[i][j] = 0.0f;
-        if (dok) {
-            const size_t zplane = (((size_t)n * g.M + m) * Dz + zd) * Hz;
-#pragma unroll 1
-            for (int it = 0; it < (WLX / PXT) * (WLY / ZR) / 64; ++it) {
-                const int item = lane + 64 * it;
-                const int q = item & (WLX / PXT - 1), rp = item / (WLX / PXT);
-                const int zy0 = ty * WLY + rp * ZR, zx0 = tx * WLX + q * PXT;
-                float zv[ZR][PXT];
-                bool any = false;
 #pragma unroll
-                for (int r = 0; r < ZR; ++r)
+        for (int it = 0; it < NIT; ++it) {
+            const int item = lane + 64 * it;
+            const int q = item & (WLX / PXT - 1), rp = item / (WLX / PXT);
+            bool any = false;
 #pragma unroll
-                    for (int p = 0; p < PXT; ++p) {
-                        const size_t zi = (zplane + zy0 + r) * Wz + zx0 + p;
-                        float v = (zy0 + r < Hz && zx0 + p < Wz) ? z[zi] : 0.0f;
-                        if (gate && v != 0.0f && gate[zi] == 0.0f) v = 0.0f;
-                        zv[r][p] = v;
-                        any |= v != 0.0f;
-                    }
-                if (!any) continue;
-                const float *xrow = xt + (rp * ZR * SW) * XW + q * PXT * SW;
+            for (int r = 0; r < ZR; ++r)
 #pragma unroll
-                for (int xr = 0; xr < NXR; ++xr) {
-                    // 16-byte LDS reads (XW and the column offset are multiples of 4 words): with 4-byte reads
-                    // every lane's address is 0 mod 4 words and a wave uses 8 of the 32 banks
-                    constexpr int WL4 = (WL + 3) / 4;
-                    float win[WL4 * 4];
-                    const float4 *x4 = reinterpret_cast<const float4 *>(xrow + xr * XW);
+                for (int p = 0; p < PXT; ++p) any |= zv[it][r][p] != 0.0f;
+            if (!any) continue;
+            const float *xrow = xt + (rp * ZR * SW) * XW + q * PXT * SW;
 #pragma unroll
-                    for (int i = 0; i < WL4; ++i) {
-                        const float4 v4 = x4[i];
-                        win[4 * i] = v4.x; win[4 * i + 1] = v4.y; win[4 * i + 2] = v4.z; win[4 * i + 3] = v4.w;
-                    }
+            for (int xr = 0; xr < NXR; ++xr) {
+                // 16-byte LDS reads (XW and the column offset are multiples of 4 words)
+                constexpr int WL4 = (WL + 3) / 4;
+                float win[WL4 * 4];
+                const float4 *x4 = reinterpret_cast<const float4 *>(xrow + xr * XW);
 #pragma unroll
-                    for (int r = 0; r < ZR; ++r) {
-                        const int ki = xr - r * SW;                    // compile-time after unrolling
-                        if (ki < 0 || ki >= PH) continue;
+                for (int i = 0; i < WL4; ++i) {
+                    const float4 v4 = x4[i];
+                    win[4 * i] = v4.x; win[4 * i + 1] = v4.y; win[4 * i + 2] = v4.z; win[4 * i + 3] = v4.w;
+                }
 #pragma unroll
-                        for (int kj = 0; kj < PW; ++kj)
+                for (int r = 0; r < ZR; ++r) {
+                    const int ki = xr - r * SW;                    // compile-time after unrolling
+                    if (ki < 0 || ki >= PH) continue;
 #pragma unroll
-                            for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[r][p], win[p * SW + kj], acc[ki][kj]);
-                    }
+                    for (int kj = 0; kj < PW; ++kj)
+#pragma unroll
+                        for (int p = 0; p < PXT; ++p) acc[ki][kj] = fmaf(zv[it][r][p], win[p * SW + kj], acc[ki][kj]);
                 }
             }
         }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int r = 0; r < ZR; ++r)
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) zv[it][r][p] = zn[it][r][p];
         // butterfly over the 64 lanes (fixed order), then lanes 0..PH*PW-1 store one tap each
         float *dst = part + (pbase + m) * (PH * PW);
 #pragma unroll

@@ -24,6 +24,12 @@ SHAPES = [
     (2, 1, 5, (8, 12, 20), (9, 9, 5), 2),
     (1, 2, 4, (6, 9, 12), (3, 3, 3), 3),
     (1, 1, 169, (16, 18), (7, 7), 2),
+    # enough 64 x 32 code tiles x (C * Pd) for the LDS-tiled filter gradient k_wgrad_l (>= 128 workgroups),
+    # with ragged tiles, C = 3, stride 2 and a 3-D filter
+    (24, 3, 5, (40, 70), (7, 7), 1),
+    (48, 1, 6, (132, 72), (7, 7), 2),
+    (3, 1, 5, (9, 40, 72), (5, 5, 5), 1),
+    (70, 2, 4, (34, 66), (9, 9), 1),
 ]
 
 
