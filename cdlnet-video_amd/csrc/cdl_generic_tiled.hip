@@ -221,6 +221,161 @@ __global__ __launch_bounds__(256) void k_synthesis_t(cdl_geom g, const float *__
 }
 
 // ------------------------------------------------------------------------------------------
+// synthesis, software-pipelined: same thread mapping and arithmetic as k_synthesis_t, but the code patch of
+// the NEXT (channel pair, kd) round is fetched into registers while the current round is multiplied, and
+// the two divisions per patch element are done once per thread instead of once per round (the element ->
+// (channel, row, column) map does not change between rounds).  k_synthesis_t runs ~30-170 rounds per
+// workgroup, each an exposed global -> LDS fill between two barriers: that, not the FMAs, was its time.
+constexpr int MQ = 2, QNE = 16;       // channels per round; patch elements per thread (register prefetch)
+
+template <int PW, int SW, int CC>
+__global__ __launch_bounds__(256) void k_synthesis_q(cdl_geom g, const float *__restrict__ z,
+                                                     const float *__restrict__ gate,
+                                                     const float *__restrict__ w, float alpha,
+                                                     const float *__restrict__ mask,
+                                                     const float *__restrict__ sub,
+                                                     float *__restrict__ out, int tilesX, int tilesY,
+                                                     int PZH, int PZW, int mper, float *__restrict__ partial)
+{
+    extern __shared__ float patch[];                       // [MQ][PZH][PZW]
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int d = b;
+    const int n = blockIdx.y;
+    const int lx = threadIdx.x & 15, lw = threadIdx.x >> 6, lr = (threadIdx.x >> 4) & 3;
+    const int ly = lw + 4 * lr;                            // rows of a wave are congruent mod 4
+    const int y = ty * TY + ly, x0 = tx * TX + lx * PXT;
+    const int pw = g.pw;
+    const int zy_lo = cdl_floordiv(ty * TY + g.ph - (g.Ph - 1), g.sh);
+    const int zx_lo = cdl_floordiv(tx * TX + pw - (PW - 1), SW);
+    const int plane = PZH * PZW, nel = MQ * plane;
+    const int taps = g.Pd * g.Ph * PW;
+    const int slab = Dz * Hz * Wz;                         // one channel of one sample (host checks MQ * slab < 2^31)
+    constexpr int B0ODD = (SW == 2) ? (((PW - 1) / 2) & 1) : 0;
+    constexpr int WLS = (PXT - 1 + PW - 1 + B0ODD) / SW + 1;
+    const int zx_first = cdl_floordiv(x0 + pw - (PW - 1), SW) - zx_lo;
+
+    // element table of this thread: offset inside the (channel pair, depth) slab, or -1 outside the code image
+    int off[QNE];
+    unsigned ch1 = 0;                                      // bit e: element e is in the second channel of the pair
+#pragma unroll
+    for (int e = 0; e < QNE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        off[e] = -1;
+        if (i < nel) {
+            const int px = i % PZW;
+            const int r = i / PZW;
+            const int py = r % PZH, mm = r / PZH;
+            const int zy = zy_lo + py, zx = zx_lo + px;
+            if (zy >= 0 && zy < Hz && zx >= 0 && zx < Wz) off[e] = mm * slab + zy * Wz + zx;
+            if (mm) ch1 |= 1u << e;
+        }
+    }
+    const int m_lo = blockIdx.z * mper, m_hi = min(g.M, m_lo + mper);   // channel slice (split launches)
+    auto advance = [&](int &m0, int &kd, int &zd) -> bool {             // next (pair, kd) round with a live depth tap
+        for (;;) {
+            if (++kd >= g.Pd) {
+                kd = 0;
+                m0 += MQ;
+            }
+            if (m0 >= m_hi) return false;
+            const int td = d + g.pd - kd;
+            if (td < 0 || td % g.sd) continue;
+            zd = td / g.sd;
+            if (zd < Dz) return true;
+        }
+    };
+    auto issue = [&](int m0, int zd, float (&pf)[QNE]) {
+        const size_t base = (((size_t)n * g.M + m0) * Dz + zd) * (size_t)Hz * Wz;
+        const bool two = m_hi - m0 > 1;
+#pragma unroll
+        for (int e = 0; e < QNE; ++e) {
+            const bool ok = off[e] >= 0 && (two || !((ch1 >> e) & 1u));
+            const size_t idx = base + (ok ? off[e] : 0);
+            float v = z[idx];
+            if (gate && gate[idx] == 0.0f) v = 0.0f;
+            pf[e] = ok ? v : 0.0f;
+        }
+    };
+
+    float acc[CC][PXT];
+    float pf[QNE];
+    for (int c0 = 0; c0 < g.C; c0 += CC) {
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int p = 0; p < PXT; ++p) acc[cc][p] = 0.0f;
+        int m0 = m_lo, kd = -1, zd = 0;
+        bool have = advance(m0, kd, zd);
+        if (have) issue(m0, zd, pf);
+        while (have) {
+            __syncthreads();                               // the previous round's readers are done
+#pragma unroll
+            for (int e = 0; e < QNE; ++e) {
+                const int i = threadIdx.x + 256 * e;
+                if (i < nel) patch[i] = pf[e];
+            }
+            __syncthreads();
+            int nm0 = m0, nkd = kd, nzd = zd;
+            const bool nhave = advance(nm0, nkd, nzd);
+            if (nhave) issue(nm0, nzd, pf);                // in flight during the multiply-adds below
+            const int mlim = min(MQ, m_hi - m0);
+            for (int ki = 0; ki < g.Ph; ++ki) {
+                const int tyy = y + g.ph - ki + g.sh * g.Ph;      // shifted positive
+                if (tyy % g.sh) continue;                          // same for every row of the wave
+                const int zyl = tyy / g.sh - g.Ph - zy_lo;
+                const int wbase = (kd * g.Ph + ki) * PW;
+                for (int mm = 0; mm < mlim; ++mm) {
+                    const float *prow = patch + mm * plane + zyl * PZW + zx_first;
+                    float win[WLS];
+#pragma unroll
+                    for (int i = 0; i < WLS; ++i) win[i] = prow[i];
+#pragma unroll
+                    for (int cc = 0; cc < CC; ++cc) {
+                        if (c0 + cc >= g.C) continue;
+                        const float *wr = w + ((size_t)(m0 + mm) * g.C + c0 + cc) * taps + wbase;   // uniform
+#pragma unroll
+                        for (int kj = 0; kj < PW; ++kj) {
+                            const float wv = wr[kj];
+#pragma unroll
+                            for (int p = 0; p < PXT; ++p) {
+                                const int t = p + PW - 1 - kj;                  // compile-time after unrolling
+                                if (SW == 1 || ((t & 1) == B0ODD))
+                                    acc[cc][p] = fmaf(win[SW == 1 ? t : (t + B0ODD) / 2], wv, acc[cc][p]);
+                            }
+                        }
+                    }
+                }
+            }
+            m0 = nm0; kd = nkd; zd = nzd; have = nhave;
+        }
+        if (y < g.H) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                const int c = c0 + cc;
+                if (c >= g.C) continue;
+                const size_t rowi = ((((size_t)n * g.C + c) * g.D + d) * g.H + y) * g.W;
+#pragma unroll
+                for (int p = 0; p < PXT; ++p) {
+                    const int xo = x0 + p;
+                    if (xo >= g.W) continue;
+                    if (partial) {          // split launch: raw channel-slice sum, folded by k_synth_fold
+                        partial[(size_t)blockIdx.z * ((size_t)g.N * g.C * g.D * g.H * g.W) + rowi + xo] = acc[cc][p];
+                        continue;
+                    }
+                    float v = alpha * acc[cc][p];
+                    if (mask) v *= mask[rowi + xo];
+                    if (sub) v -= sub[rowi + xo];
+                    out[rowi + xo] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // filter gradient: one workgroup per (m, c, kd, ki) filter row as in the untiled kernel, but every
 // thread takes 4 consecutive code columns per step (one row window of the image feeds 4*PW FMAs)
 // and all-zero quads of the sparse / gated code are skipped.  Fixed reduction order.
@@ -626,7 +781,36 @@ int launch_synthesis_m(const cdl_geom *g, const float *z, const float *gate, con
 template <int PW, int SW, int CC>
 int launch_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                      const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream)
-{
+{    {   // pipelined kernel when a thread can hold its share of a two-channel patch in registers
+        const int PZH = (TY - 1 + g->Ph - 1) / g->sh + 2;
+        const int PZW = (TX - 1 + PW - 1) / SW + 2 + 4;
+        const size_t slab = (size_t)(g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
+        // measured (rocprofv3, per launch): cfg3 3-D 1.34 -> 1.11 ms, cfg4 C=3 0.50 -> 0.46 ms, but the 2-D C=1
+        // M=169 stride-2 shape 1.02 -> 1.89 ms (4x the rounds and barriers of the 8-channel kernel for little
+        // work per round): pipelined only where a round carries Pd or C times more work
+        if ((g->Pd > 1 || g->C > 1) && MQ * PZH * PZW <= QNE * 256 && MQ * slab < ((size_t)1 << 31) &&
+            !getenv("CDL_NO_PIPELINED_SYNTHESIS")) {
+            const int tilesX = (g->W + TX - 1) / TX, tilesY = (g->H + TY - 1) / TY;
+            const size_t lds = (size_t)MQ * PZH * PZW * sizeof(float);
+            int chunks;
+            int mper = channel_split(g->M, (long)tilesX * tilesY * g->D * g->N, &chunks);
+            const size_t total = (size_t)g->N * g->C * g->D * g->H * g->W;
+            if (chunks > 1 && (!ws || ws_floats < (size_t)chunks * total)) {
+                chunks = 1;
+                mper = g->M;
+            }
+            dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N, (unsigned)chunks);
+            k_synthesis_q<PW, SW, CC><<<grid, 256, lds, S(stream)>>>(*g, z, gate, w, alpha, mask, sub, out, tilesX,
+                                                                  tilesY, PZH, PZW, mper, chunks > 1 ? ws : nullptr);
+            CDL_LAUNCH_CHECK();
+            if (chunks > 1) {
+                k_synth_fold<<<(unsigned)((total + 255) / 256), 256, 0, S(stream)>>>(ws, mask, sub, alpha, out, chunks, total);
+                CDL_LAUNCH_CHECK();
+            }
+            return 0;
+        }
+    }
+
     // measured on cfg3 (3-D, 5x5x5): 2 channels per LDS round 30.7 ms forward, 4: 33.5, 8: 37.5; no effect in 2-D
     if (g->Pd > 1) return launch_synthesis_m<PW, SW, CC, 2>(g, z, gate, w, alpha, mask, sub, out, ws, ws_floats, stream);
     return launch_synthesis_m<PW, SW, CC, 8>(g, z, gate, w, alpha, mask, sub, out, ws, ws_floats, stream);
