@@ -60,6 +60,8 @@ SIGNATURES = {
     "cdl_fused2d_prep": [_P, _P, _P, _I, _I, _P],
     "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "cdl_fused2d_support_map": [_G, _P, _P, _P],
+    "cdl_fused2d_timing": [_I],
+    "cdl_fused2d_timing_read": [ctypes.POINTER(ctypes.c_double), _IP],
     "cdl_fused2d_assemble": [_G, _P, _P, _P, _F, _P, _P],
     "cdl_fused2d_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "cdl_fused2d_dtau_reduce": [_G, _P, _P, _P, _P, _P],

@@ -29,6 +29,8 @@
 // patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
 #include <cstdlib>
+#include <vector>
+
 #include "cdl_common.h"
 
 namespace {
@@ -1263,6 +1265,70 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
     return 0;
 }
 
+}  // extern "C"
+
+/* ---- optional per-kernel timing inside the sweeps (HIP events on the launch stream) -------------------
+ * bench.py turns it on for a few steps to report the in-step average duration of the three fat kernels
+ * (isolated re-launches of one kernel miss the cache state the step leaves behind).  Off: no events. */
+namespace {
+struct TimingState {
+    bool on = false;
+    std::vector<hipEvent_t> pool;          // start/stop pairs, in launch order
+    std::vector<int> cls;                  // class of pair i: 0 forward stage (k >= 1), 1 reverse stage,
+                                           // 2 filter gradients, 3 first forward stage (k = 0: no fat read)
+    size_t used = 0;
+};
+TimingState g_timing;
+
+struct TimingScope {
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    TimingScope(int c, hipStream_t s) : st(s)
+    {
+        if (!g_timing.on) return;
+        while (g_timing.pool.size() < 2 * (g_timing.used + 1)) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            g_timing.pool.push_back(e);
+        }
+        (void)hipEventRecord(g_timing.pool[2 * g_timing.used], st);
+        stop = g_timing.pool[2 * g_timing.used + 1];
+        g_timing.cls.push_back(c);
+        ++g_timing.used;
+    }
+    ~TimingScope()
+    {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
+}  // namespace
+
+extern "C" int cdl_fused2d_timing(int enable)
+{
+    g_timing.on = enable != 0;
+    if (enable) {
+        g_timing.used = 0;
+        g_timing.cls.clear();
+    }
+    return 0;
+}
+
+extern "C" int cdl_fused2d_timing_read(double *ms_sum, int *count)
+{
+    if (!ms_sum || !count) return CDL_EINVAL;
+    for (int c = 0; c < 4; ++c) { ms_sum[c] = 0.0; count[c] = 0; }
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        float ms = 0.0f;
+        hipError_t e = hipEventSynchronize(g_timing.pool[2 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_timing.pool[2 * i], g_timing.pool[2 * i + 1]);
+        if (e != hipSuccess) return -(int)e;
+        ms_sum[g_timing.cls[i]] += ms;
+        ++count[g_timing.cls[i]];
+    }
+    return 0;
+}
+
+extern "C" {
 /* ---- whole sweeps: every launch of a forward / reverse pass enqueued from one C call ----------------
  * Snake order: consecutive fat launches walk the tiles in opposite directions, so each one starts on
  * the bytes the previous one touched last, which are still in the 256 MiB Infinity Cache (it holds
@@ -1312,9 +1378,12 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
     if (rc) return rc;
     for (int k = 0; k < K; ++k) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
-        rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k],
-                                  patches, maps ? maps[k] : nullptr,
-                                  precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+        {
+            TimingScope ts(k ? 0 : 3, S(stream));
+            rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k],
+                                      patches, maps ? maps[k] : nullptr,
+                                      precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+        }
         if (rc) return rc;
         if (k < K - 1) {
             rc = cdl_fused2d_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
@@ -1354,14 +1423,20 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
     for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         float *duk = du[flip];
-        rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1, sprec, stream);
+        {
+            TimingScope ts(1, S(stream));
+            rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1, sprec, stream);
+        }
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
         if (rc) return rc;
         if (k >= 1) {
             rc = cdl_fused2d_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
             if (rc) return rc;
-            rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wprec, stream);
+            {
+                TimingScope ts(2, S(stream));
+                rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wprec, stream);
+            }
             thin = q;
         } else {
             rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws, wprec, stream);

@@ -614,3 +614,18 @@ def ista_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt,
         _ptr(g0), _ptr(g1), _ptr(q), _ptr(ws), n, _stream())
     _lib.check(rc, "cdl_ista_backward")
     return dA, dB
+
+
+def fused_timing(enable: bool):
+    """Start / stop the HIP-event timing of the fused sweeps' fat kernels (cdl_fused2d_timing)."""
+    _lib.check(_lib.lib().cdl_fused2d_timing(1 if enable else 0), "cdl_fused2d_timing")
+
+
+def fused_timing_read():
+    """{class: (average ms, launches)} for the forward stage, reverse stage and filter-gradient launches
+    recorded since fused_timing(True)."""
+    ms = (ctypes.c_double * 4)()
+    cnt = (ctypes.c_int * 4)()
+    _lib.check(_lib.lib().cdl_fused2d_timing_read(ms, cnt), "cdl_fused2d_timing_read")
+    names = ("stage_fwd", "stage_bwd", "wgrad", "stage_first")
+    return {n: ((ms[i] / cnt[i]) if cnt[i] else 0.0, int(cnt[i])) for i, n in enumerate(names)}

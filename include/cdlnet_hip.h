@@ -285,6 +285,13 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
                          float *du0, float *du1, float *q, void *frags, float *patches,
                          float *dtau_partial, float *wgrad_ws, int precision, void *stream);
 
+/* Per-kernel timing inside the fused sweeps: cdl_fused2d_timing(1) starts collecting HIP-event pairs around
+ * every forward stage (class 0; the k = 0 launch, which reads no code, is class 3), reverse stage (1) and
+ * filter-gradient (2) launch of the sweeps on their own stream, cdl_fused2d_timing(0) stops; _read synchronises and returns the summed milliseconds and launch counts
+ * per class.  For measurement (bench.py); off by default, no events are recorded then. */
+int cdl_fused2d_timing(int enable);
+int cdl_fused2d_timing_read(double *ms_sum /*4*/, int *count /*4*/);
+
 #ifdef __cplusplus
 }
 #endif
