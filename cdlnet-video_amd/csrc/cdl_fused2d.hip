@@ -949,12 +949,13 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 }
 
 // dw[ch][i'][j'] = alpha * sum_g partial[g][op][ch][8(i'+off) + (j'+off)].  32 outputs per workgroup,
-// 8 strided partial sums each, combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int G,
-                                                      float *__restrict__ dw0, float alpha0,
-                                                      float *__restrict__ dw1, float alpha1, int M, int P)
+// 32 strided partial sums each (1024 threads: the kernel is latency-bound, 16 loads per thread), combined
+// in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float *__restrict__ partial, int G,
+                                                       float *__restrict__ dw0, float alpha0,
+                                                       float *__restrict__ dw1, float alpha1, int M, int P)
 {
-    __shared__ float red[8][32];
+    __shared__ float red[32][33];
     const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int t = blockIdx.x * 32 + o;
     const int per = M * P * P;
@@ -965,34 +966,34 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
         op = t / per; r = t % per;
         const int ch = r / (P * P), ij = r % (P * P), off = (7 - P) / 2;
         const int tap = 8 * (ij / P + off) + (ij % P + off);
-        for (int g = part; g < G; g += 8) sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
+        for (int g = part; g < G; g += 32) sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
     }
     red[part][o] = sum;
     __syncthreads();
     if (part == 0 && live) {
         float *dw = op ? dw1 : dw0;
         if (dw) {
-            const float tot = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) +
-                              ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+            float tot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) tot += red[k][o];
             dw[r] = (op ? alpha1 : alpha0) * tot;
         }
     }
 }
 
-// dt0[m] = sum_rows partial[row][m]; dt1[m] = sum_rows c[row / per_img] * partial[row][m].
-// One workgroup per 4 channels: 64 row-strided partial sums per channel, then a fixed-order tree
-// (deterministic).
-__global__ __launch_bounds__(256) void k_dtau_reduce(const float *__restrict__ partial,
-                                                     const float *__restrict__ c, float *__restrict__ dt0,
-                                                     float *__restrict__ dt1, int N, int per_img, int M)
+// dt0[m] = sum over workgroups; dt1[m] = sum_n c[n] * (sum over the workgroups of image n).  4 channels x 256
+// row-strided partial sums per workgroup, tree-combined in a fixed order.
+__global__ __launch_bounds__(1024) void k_dtau_reduce(const float *__restrict__ partial,
+                                                      const float *__restrict__ c, float *__restrict__ dt0,
+                                                      float *__restrict__ dt1, int N, int per_img, int M)
 {
-    __shared__ float r0[64][4], r1[64][4];
+    __shared__ float r0[256][4], r1[256][4];
     const int mi = threadIdx.x & 3, part = threadIdx.x >> 2;
     const int m = blockIdx.x * 4 + mi;
     float a0 = 0.0f, a1 = 0.0f;
     const int rows = N * per_img;
     if (m < M)
-        for (int row = part; row < rows; row += 64) {
+        for (int row = part; row < rows; row += 256) {
             const float v = partial[(size_t)row * M + m];
             a0 += v;
             if (c) a1 = fmaf(c[row / per_img], v, a1);
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_dtau_reduce(const float *__restrict__ p
     r0[part][mi] = a0;
     r1[part][mi] = a1;
     __syncthreads();
-    for (int stride = 32; stride >= 1; stride >>= 1) {
+    for (int stride = 128; stride >= 1; stride >>= 1) {
         if (part < stride) { r0[part][mi] += r0[part + stride][mi]; r1[part][mi] += r1[part + stride][mi]; }
         __syncthreads();
     }
@@ -1209,7 +1210,7 @@ int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const 
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
-    k_dtau_reduce<<<(g->M + 3) / 4, 256, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, tiles_x(g) * tiles_y(g), g->M);
+    k_dtau_reduce<<<(g->M + 3) / 4, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, tiles_x(g) * tiles_y(g), g->M);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1243,7 +1244,7 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     else rc = precision == 0 ? launch_wgrad<1, 0>(p, G, S(stream)) : launch_wgrad<1, 1>(p, G, S(stream));
     if (rc) return rc;
     const int total = 2 * g->M * g->Ph * g->Pw;
-    k_wgrad_reduce<<<(total + 31) / 32, 256, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
+    k_wgrad_reduce<<<(total + 31) / 32, 1024, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
                                                              X1 ? dw1 : nullptr, alpha1, g->M, g->Ph);
     CDL_LAUNCH_CHECK();
     return 0;
