@@ -54,6 +54,7 @@ SIGNATURES = {
     "cdl_prox_csr": [_G, _P, _P, _P, _P, _P, _P, _P, _P],
     "cdl_prox_csr_bwd": [_G] + [_P] * 15 + [ctypes.c_size_t, _P],
     "cdl_project_filters": [_P, _I, _I, _P],
+    "cdl_project_filter_banks": [_P, _I, _I, _I, _P],
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_fused2d_supported": [_G],

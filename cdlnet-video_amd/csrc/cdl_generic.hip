@@ -403,6 +403,23 @@ __global__ __launch_bounds__(64) void k_project(float *__restrict__ w, int flen)
         for (int i = threadIdx.x; i < flen; i += 64) f[i] *= scale;
 }
 
+// the same for up to 64 banks of identical shape in one launch (bank = blockIdx.y): project() of a K = 30 net
+// is 60 banks, i.e. 60 launches of a 4 us kernel otherwise
+constexpr int PROJECT_BATCH = 64;
+struct ProjectBatch {
+    float *w[PROJECT_BATCH];
+};
+__global__ __launch_bounds__(64) void k_project_batch(ProjectBatch b, int flen)
+{
+    float *f = b.w[blockIdx.y] + (size_t)blockIdx.x * flen;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < flen; i += 64) ss = fmaf(f[i], f[i], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    float scale = fminf(1.0f / sqrtf(ss), 1.0f);
+    if (scale < 1.0f)
+        for (int i = threadIdx.x; i < flen; i += 64) f[i] *= scale;
+}
+
 // ------------------------------------------------------------------------------------------
 // Gabor dictionary synthesis and its adjoint
 __global__ void k_gabor(const float *__restrict__ alpha, const float *__restrict__ a,
@@ -659,6 +676,22 @@ int cdl_project_filters(float *w, int nfilters, int flen, void *stream)
     if (!w || nfilters <= 0 || flen <= 0) return CDL_EINVAL;
     k_project<<<nfilters, 64, 0, S(stream)>>>(w, flen);
     CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_project_filter_banks(float *const *w, int nbanks, int nfilters, int flen, void *stream)
+{
+    if (!w || nbanks <= 0 || nfilters <= 0 || flen <= 0) return CDL_EINVAL;
+    for (int b0 = 0; b0 < nbanks; b0 += PROJECT_BATCH) {
+        const int nb = nbanks - b0 < PROJECT_BATCH ? nbanks - b0 : PROJECT_BATCH;
+        ProjectBatch pb = {};
+        for (int i = 0; i < nb; ++i) {
+            if (!w[b0 + i]) return CDL_EINVAL;
+            pb.w[i] = w[b0 + i];
+        }
+        k_project_batch<<<dim3((unsigned)nfilters, (unsigned)nb), 64, 0, S(stream)>>>(pb, flen);
+        CDL_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -159,9 +159,7 @@ class CDLNet(_ISTANet):
     def project(self):
         """l2-ball projection of every filter, R+ projection of the thresholds (net.py:66-74)."""
         self.t.clamp_(0.0)
-        for k in range(self.K):
-            ops.project_filters_(self.A[k].weight.data)
-            ops.project_filters_(self.B[k].weight.data)
+        ops.project_filter_banks_([m.weight.data for m in self.A] + [m.weight.data for m in self.B])
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """Accepts upstream CDLNet-OJSP checkpoints that predate the unused `g` parameter."""
@@ -227,9 +225,7 @@ class _CSRBase(_ISTANet):
     def project(self):
         """net.py:419-424 / 518-523: only `t`, `A`, `B` are projected (not t2, g*, A2, B2)."""
         self.t.clamp_(0.0)
-        for k in range(self.K):
-            ops.project_filters_(self.A[k].weight.data)
-            ops.project_filters_(self.B[k].weight.data)
+        ops.project_filter_banks_([m.weight.data for m in self.A] + [m.weight.data for m in self.B])
 
     def _prep(self, y, sigma, mask):
         if not y.is_cuda:
@@ -344,9 +340,7 @@ class CDLNetVideo(_ISTANet):
         """net.py:184-190.  (The reference's own call raises on torch >= 2: `torch.norm` with a
         3-axis `dim`; this does what it evidently means -- the l2 norm over the filter volume.)"""
         self.t.clamp_(0.0)
-        for k in range(self.K):
-            ops.project_filters_(self.A[k].weight.data)
-            ops.project_filters_(self.B[k].weight.data)
+        ops.project_filter_banks_([m.weight.data for m in self.A] + [m.weight.data for m in self.B])
 
 
 # ------------------------------------------------------------------------------------------ Gabor

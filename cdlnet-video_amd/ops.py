@@ -329,6 +329,21 @@ def project_filters_(w):
     return w
 
 
+def project_filter_banks_(banks):
+    """In-place unit-ball projection of every filter of every bank (same-shaped (M,C,*P) tensors): one launch."""
+    banks = list(banks)
+    if not banks:
+        return
+    w0 = banks[0]
+    for w in banks:
+        if not w.is_cuda:
+            raise RuntimeError("project(): parameters must live on the ROCm device (no CPU path)")
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.shape == w0.shape
+    nf = w0.shape[0] * w0.shape[1]
+    rc = _lib.lib().cdl_project_filter_banks(_ptr_table(banks), len(banks), nf, w0.numel() // nf, _stream())
+    _lib.check(rc, "cdl_project_filter_banks")
+
+
 def gabor_filters(alpha, a, w0, psi, P, transpose):
     alpha, a, w0, psi = (_dev(v, n) for v, n in ((alpha, "alpha"), (a, "a"), (w0, "w0"), (psi, "psi")))
     order, M, C = psi.shape

@@ -193,6 +193,9 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
 /* model/solvers.py:24-28 (uball_project) applied by net.py:72-73,189-190: every filter
  * (consecutive `flen` floats) with l2 norm > 1 is scaled onto the unit sphere.  w inout. */
 int cdl_project_filters(float *w, int nfilters, int flen, void *stream);
+/* The same for `nbanks` banks of identical shape (HOST array of device pointers) in one launch per 64 banks:
+ * net.py:72-73 projects A[k] and B[k] for every k. */
+int cdl_project_filter_banks(float *const *w, int nbanks, int nfilters, int flen, void *stream);
 
 /* model/gabor.py:7-28,46-51 (gabor_kernel, get_filter): w[m,c,i,j] = sum_o alpha[o,m,c] *
  * exp(-(a0*(i-x0))^2 - (a1*(j-x0))^2) * cos(sgn*(w00*(i-x0) + w01*(j-x0) + psi)),
