@@ -591,10 +591,20 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
     return 0;
 }
 
+// the matrix-core synthesis (cdl_synth_mfma.hip) is the default wherever it has a kernel; CDL_MFMA_SYNTHESIS=0
+// selects the fp32 VALU kernels (read per call, so one process can compare both)
+static bool mfma_synthesis_enabled()
+{
+    const char *e = getenv("CDL_MFMA_SYNTHESIS");
+    return !(e && e[0] == '0');
+}
+
 size_t cdl_synthesis_workspace_floats(const cdl_geom *g)
 {
     if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
-    return cdl_tiled_synthesis_ws_floats(g);
+    const size_t a = cdl_tiled_synthesis_ws_floats(g);
+    const size_t b = mfma_synthesis_enabled() ? cdl_mfma_synthesis_ws_floats(g) : 0;
+    return a > b ? a : b;
 }
 
 int cdl_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
@@ -609,6 +619,10 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
 {
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
+        if (mfma_synthesis_enabled()) {
+            const int rcm = cdl_mfma_synthesis(g, z, gate, w, alpha, mask, sub, out, workspace, workspace_floats, stream);
+            if (rcm != CDL_EUNSUPPORTED) return rcm;
+        }
         const int rc = cdl_tiled_synthesis(g, z, gate, w, alpha, mask, sub, out, workspace, workspace_floats,
                                            stream);
         if (rc != CDL_EUNSUPPORTED) return rc;

@@ -1,0 +1,278 @@
+// Synthesis (transposed convolution) on the matrix cores for the shapes the fused 2-D kernel does not take:
+// any C, 2-D or 3-D, stride 1 or 2, odd square filter planes up to 9 x 9 (reference F.conv_transpose2d/3d at
+// model/net.py:87,90,205,210).
+//
+//   col[tap][px] = sum_m W^T[tap][m] * z[m][px]          one GEMM per (image channel c, depth tap kd):
+//                                                        M_dim = Ph*Pw taps (no padding waste beyond 32-row tiles),
+//                                                        K_dim = code channels, N_dim = 32 code pixels per block
+//   out[c][d][Y][X] += col[(ki,kj)][(Y+ph-ki)/s, (X+pw-kj)/s]   (col2im)
+//
+// A workgroup owns a 32 x 8 tile of code pixels of one (n, zd).  Per (c, kd) group its 8 waves run the GEMM for
+// one pixel row each (split-bf16 x3 like the fused kernel: fp32-grade), park the accumulator tiles in an LDS `col`
+// tile and then gather them, in a fixed order, into the workgroup's output patch ((8-1)s+Ph rows x (32-1)s+Pw
+// columns, thin).  Patches of neighbouring tiles and depth taps overlap; k_synth_assemble adds them in a
+// fixed order (deterministic, no atomics) and applies alpha, mask and sub.  The fat tensor is read with no halo.
+#include "cdl_common.h"
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TCX = 32, TCY = 8;      // code-pixel tile of a workgroup: 8 blocks of 32 pixels, one per wave
+constexpr int SNT = 64 * TCY;         // 8 waves: with 64-108 KB of LDS only one workgroup fits a CU
+constexpr int KSC = 4;                // k-steps whose code values are loaded together (32 loads in flight per lane)
+
+// ------------------------------------------------------------------------------------------
+// filters (M, C, Pd, Ph, Pw) -> MFMA A-operand fragments of W^T per (c, kd) group:
+// frag[((g*RT + R)*KS + ks)*2 + hl][lane] (16 B): lane (row = tap 32R + (lane & 31), h = lane >> 5) holds the 8
+// channels m = 16ks + 8h + i of that tap (zero beyond M or Ph*Pw), hi or lo bf16 part.
+__global__ void k_synth_prep(const float *__restrict__ w, uint4 *__restrict__ frags, int M, int C, int Pd,
+                             int taps, int RT, int KS)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = C * Pd * RT * KS * 64;
+    if (t >= total) return;
+    const int lane = t & 63;
+    int r = t >> 6;
+    const int ks = r % KS; r /= KS;
+    const int R = r % RT; r /= RT;
+    const int g = r;                                        // c * Pd + kd
+    const int row = lane & 31, h = lane >> 5;
+    const int tap = 32 * R + row;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = 16 * ks + 8 * h + i;
+        float v = 0.0f;
+        if (m < M && tap < taps) v = w[((size_t)m * C * Pd + g) * taps + tap];
+        const __bf16 hh = (__bf16)v;
+        hi[i] = hh;
+        lo[i] = (__bf16)(v - (float)hh);
+    }
+    const size_t base = (((size_t)g * RT + R) * KS + ks) * 2;
+    frags[(base + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    frags[(base + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+// ------------------------------------------------------------------------------------------
+template <int PH, int PW, int SW>
+__global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__restrict__ z,
+                                                 const float *__restrict__ gate, const uint4 *__restrict__ frags,
+                                                 float *__restrict__ patches, int tilesX, int tilesY, int KS)
+{
+    constexpr int T = PH * PW, RT = (T + 31) / 32;
+    constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *col = reinterpret_cast<float *>(smem);                              // [RT*32][TCX*TCY]
+    uint4 *wl = reinterpret_cast<uint4 *>(smem + (size_t)RT * 32 * TCX * TCY * 4);   // [RT][KS][2][64]
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b % Dz, n = b / Dz;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c32 = lane & 31, h = lane >> 5;
+    const int G = g.C * g.Pd;
+    const size_t slab = (size_t)Dz * Hz * Wz;                                  // one code channel of one sample
+    const size_t zbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
+    const int cx = tx * TCX + c32;
+    const int nfr = RT * KS * 2 * 64;                                          // uint4 fragments per group
+
+    for (int grp = 0; grp < G; ++grp) {
+        const int kd = grp % g.Pd;
+        const int d = zd * g.sd - g.pd + kd;
+        if (d < 0 || d >= g.D) continue;                    // uniform: this depth tap falls outside the image
+        __syncthreads();                                    // previous group's gather has read col
+        for (int i = threadIdx.x; i < nfr; i += SNT) wl[i] = frags[(size_t)grp * nfr + i];
+        __syncthreads();
+        {
+            const int blk = wv;                             // code row of this wave's block inside the tile
+            const int cy = ty * TCY + blk;
+            const bool ok = cy < Hz && cx < Wz;
+            const size_t poff = zbase + (size_t)(ok ? cy : 0) * Wz + (ok ? cx : 0);
+            f32x16 acc[RT];
+#pragma unroll
+            for (int R = 0; R < RT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+            for (int ks0 = 0; ks0 < KS; ks0 += KSC) {
+                float zv[KSC][8];
+#pragma unroll
+                for (int q = 0; q < KSC; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = 16 * (ks0 + q) + 8 * h + i;
+                        const bool live = ok && m < g.M;
+                        const size_t idx = poff + (size_t)(live ? m : 0) * slab;
+                        float v = z[idx];
+                        if (gate && gate[idx] == 0.0f) v = 0.0f;
+                        zv[q][i] = live ? v : 0.0f;
+                    }
+#pragma unroll
+                for (int q = 0; q < KSC; ++q) {
+                    const int ks = ks0 + q;
+                    if (ks >= KS) break;
+                    bf16x8 bh, bl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const __bf16 hh = (__bf16)zv[q][i];
+                        bh[i] = hh;
+                        bl[i] = (__bf16)(zv[q][i] - (float)hh);
+                    }
+#pragma unroll
+                    for (int R = 0; R < RT; ++R) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 0) * 64 + lane]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 1) * 64 + lane]);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
+                    }
+                }
+            }
+            // accumulator register v of tile R is tap 32R + 8(v>>2) + 4h + (v&3) of pixel column c32
+#pragma unroll
+            for (int R = 0; R < RT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int tap = 32 * R + 8 * (v >> 2) + 4 * h + (v & 3);
+                    col[tap * (TCX * TCY) + blk * TCX + c32] = acc[R][v];
+                }
+        }
+        __syncthreads();
+        // col2im into the patch of this (tile, group): fixed (ki, kj) order per output
+        float *patch = patches + ((size_t)blockIdx.x * G + grp) * (PY * PX);
+        for (int o = threadIdx.x; o < PY * PX; o += SNT) {
+            const int Yl = o / PX, Xl = o % PX;
+            float sum = 0.0f;
+            // ki = Yl - SW*zy with 0 <= zy < TCY, 0 <= ki < PH
+            for (int zy = (Yl >= PH ? (Yl - PH + SW) / SW : 0); zy < TCY && SW * zy <= Yl; ++zy) {
+                const int ki = Yl - SW * zy;
+                for (int zx = (Xl >= PW ? (Xl - PW + SW) / SW : 0); zx < TCX && SW * zx <= Xl; ++zx) {
+                    const int kj = Xl - SW * zx;
+                    sum += col[(ki * PW + kj) * (TCX * TCY) + zy * TCX + zx];
+                }
+            }
+            patch[o] = sum;
+        }
+    }
+}
+
+// out[n][c][d][Y][X] = mask * alpha * sum over depth taps and covering tiles of the patches - sub
+template <int PH, int PW, int SW>
+__global__ __launch_bounds__(256) void k_synth_assemble(cdl_geom g, const float *__restrict__ patches,
+                                                        const float *__restrict__ mask,
+                                                        const float *__restrict__ sub, float alpha,
+                                                        float *__restrict__ out, int tilesX, int tilesY)
+{
+    constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= g.W) return;
+    const int Y = blockIdx.y;
+    int r = blockIdx.z;
+    const int d = r % g.D; r /= g.D;
+    const int c = r % g.C, n = r / g.C;
+    const int Dz = g.D / g.sd, G = g.C * g.Pd;
+    // tiles whose patch covers Y: 0 <= Y + ph - ty*TCY*SW < PY   (same for X)
+    const int ay = Y + g.ph, ax = X + g.pw;
+    const int ty_hi = min(tilesY - 1, ay / (TCY * SW)), ty_lo = max(0, (ay - PY + TCY * SW) / (TCY * SW));
+    const int tx_hi = min(tilesX - 1, ax / (TCX * SW)), tx_lo = max(0, (ax - PX + TCX * SW) / (TCX * SW));
+    float sum = 0.0f;
+    for (int kd = 0; kd < g.Pd; ++kd) {
+        const int td = d + g.pd - kd;
+        if (td < 0 || td % g.sd) continue;
+        const int zd = td / g.sd;
+        if (zd >= Dz) continue;
+        const int grp = c * g.Pd + kd;
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+            const int Yl = ay - ty * TCY * SW;
+            for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                const int Xl = ax - tx * TCX * SW;
+                const size_t tile = (((size_t)n * Dz + zd) * tilesY + ty) * tilesX + tx;
+                sum += patches[((tile * G + grp) * PY + Yl) * PX + Xl];
+            }
+        }
+    }
+    const size_t i = ((((size_t)n * g.C + c) * g.D + d) * g.H + Y) * g.W + X;
+    float v = alpha * sum;
+    if (mask) v *= mask[i];
+    if (sub) v -= sub[i];
+    out[i] = v;
+}
+
+struct Plan {
+    int tilesX, tilesY, RT, KS;
+    size_t tiles, frag_uint4, patch_floats, lds;
+};
+
+bool plan_for(const cdl_geom *g, Plan *p)
+{
+    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
+    const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    p->tilesX = (Wz + TCX - 1) / TCX;
+    p->tilesY = (Hz + TCY - 1) / TCY;
+    p->RT = (g->Ph * g->Pw + 31) / 32;
+    p->KS = (g->M + 15) / 16;
+    p->tiles = (size_t)g->N * Dz * p->tilesX * p->tilesY;
+    p->frag_uint4 = (size_t)g->C * g->Pd * p->RT * p->KS * 2 * 64;
+    const int PY = (TCY - 1) * g->sh + g->Ph, PX = (TCX - 1) * g->sw + g->Pw;
+    p->patch_floats = p->tiles * g->C * g->Pd * PY * PX;
+    p->lds = (size_t)p->RT * 32 * TCX * TCY * 4 + (size_t)p->RT * p->KS * 2 * 64 * 16;
+    if (p->lds > 150 * 1024) return false;
+    if (p->tiles >= ((size_t)1 << 31) || g->H > 65535 || (size_t)g->N * g->C * g->D > 65535) return false;
+    if (p->patch_floats > ((size_t)1 << 28)) return false;                     // 1 GiB of patches: not worth it
+    return true;
+}
+
+template <int PH, int PW, int SW>
+int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, const float *w, float alpha,
+           const float *mask, const float *sub, float *out, float *ws, hipStream_t st)
+{
+    uint4 *frags = reinterpret_cast<uint4 *>(ws);                               // 16-byte aligned: ws from hipMalloc
+    float *patches = ws + p.frag_uint4 * 4;
+    const int nprep = g->C * g->Pd * p.RT * p.KS * 64;
+    k_synth_prep<<<(nprep + 255) / 256, 256, 0, st>>>(w, frags, g->M, g->C, g->Pd, g->Ph * g->Pw, p.RT, p.KS);
+    CDL_LAUNCH_CHECK();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_synth_m<PH, PW, SW><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
+    CDL_LAUNCH_CHECK();
+    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
+    k_synth_assemble<PH, PW, SW><<<grid, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// workspace (floats) of the MFMA synthesis for this geometry, 0 when it has no such kernel
+size_t cdl_mfma_synthesis_ws_floats(const cdl_geom *g)
+{
+    Plan p;
+    if (!plan_for(g, &p)) return 0;
+    return p.frag_uint4 * 4 + p.patch_floats;
+}
+
+// CDL_EUNSUPPORTED: the caller falls back to the VALU kernels
+int cdl_mfma_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
+                       const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream)
+{
+    Plan p;
+    if (!plan_for(g, &p) || !ws || ws_floats < p.frag_uint4 * 4 + p.patch_floats) return CDL_EUNSUPPORTED;
+    if ((reinterpret_cast<size_t>(ws) & 15) != 0) return CDL_EUNSUPPORTED;
+#define CDL_M(P_, S_)                                                                                  \
+    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, z, gate, w, alpha, mask, sub, out, ws, S(stream))
+    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
+    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#undef CDL_M
+    return CDL_EUNSUPPORTED;
+}

@@ -64,8 +64,12 @@ def test_analysis_variants(N, C, M, sp, P, s):
           gup * (z != 0) + ref_conv, 2e-6)
 
 
+@pytest.mark.parametrize("path,tol", [("mfma", 2e-5), ("valu", 2e-6)])
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
-def test_synthesis_variants(N, C, M, sp, P, s):
+def test_synthesis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
+    """Both synthesis paths: the matrix-core kernels (split-bf16 x3; default wherever they exist, the other
+    shapes fall through to the VALU kernels) and the fp32 VALU kernels (CDL_MFMA_SYNTHESIS=0, read per call)."""
+    monkeypatch.setenv("CDL_MFMA_SYNTHESIS", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=1)
     pad = tuple(p // 2 for p in P)
@@ -74,12 +78,14 @@ def test_synthesis_variants(N, C, M, sp, P, s):
     assert ref.shape == x.shape
     mask = (torch.rand(x.shape) < 0.4).float()
     zd, wd = z.cuda(), w.cuda()
-    tag = f"synthesis N{N}C{C}M{M}{sp}P{P}s{s}"
-    check(tag + " plain", o.synthesis(geom, zd, wd), ref, 2e-6)
-    check(tag + " resid", o.synthesis(geom, zd, wd, 1.0, None, mask.cuda(), x.cuda()), mask * ref - x, 2e-6)
+    tag = f"synthesis[{path}] N{N}C{C}M{M}{sp}P{P}s{s}"
+    check(tag + " plain", o.synthesis(geom, zd, wd), ref, tol)
+    check(tag + " resid", o.synthesis(geom, zd, wd, 1.0, None, mask.cuda(), x.cuda()), mask * ref - x, tol)
     gup = torch.randn(z.shape)
     ref_b = -mask * O.synthesis(gup * (z != 0), w, s, pad)
-    check(tag + " bwd", o.synthesis(geom, gup.cuda(), wd, -1.0, zd, mask.cuda(), None), ref_b, 2e-6)
+    check(tag + " bwd", o.synthesis(geom, gup.cuda(), wd, -1.0, zd, mask.cuda(), None), ref_b, tol)
+    # deterministic: patches are gathered and added in a fixed order
+    assert torch.equal(o.synthesis(geom, zd, wd), o.synthesis(geom, zd, wd))
 
 
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
