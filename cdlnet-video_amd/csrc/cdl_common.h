@@ -110,5 +110,9 @@ size_t cdl_tiled_synthesis_ws_floats(const cdl_geom *g);
 int cdl_mfma_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                        const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream);
 size_t cdl_mfma_synthesis_ws_floats(const cdl_geom *g);
+// matrix-core filter gradients (cdl_wgrad_mfma.hip), same convention
+int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                   float *ws, size_t ws_floats, void *stream);
+size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g);
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
                     float *dw, float *workspace, size_t workspace_floats, void *stream);

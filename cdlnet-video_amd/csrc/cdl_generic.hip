@@ -646,6 +646,13 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
     return 0;
 }
 
+// matrix-core filter gradients are the default wherever they have a kernel; CDL_MFMA_WGRAD=0 selects the VALU ones
+static bool mfma_wgrad_enabled()
+{
+    const char *e = getenv("CDL_MFMA_WGRAD");
+    return !(e && e[0] == '0');
+}
+
 size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
 {
     if (!cdl_geom_ok(g)) return 0;
@@ -655,7 +662,9 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
     // k_wgrad_l: one partial filter bank per 64 x 32 tile of code pixels (cdl_generic_tiled.hip)
     const size_t tiles = (size_t)g->N * (g->D / g->sd) * ((g->W / g->sw + 63) / 64) * ((g->H / g->sh + 31) / 32);
     const size_t by_tiles = tiles <= 4096 ? tiles * total : 0;                   // <= a few tens of MB
-    return by_rows > by_tiles ? by_rows : by_tiles;
+    const size_t by_mfma = mfma_wgrad_enabled() ? cdl_mfma_wgrad_ws_floats(g) : 0;  // cdl_wgrad_mfma.hip
+    const size_t a = by_rows > by_tiles ? by_rows : by_tiles;
+    return a > by_mfma ? a : by_mfma;
 }
 
 int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
@@ -664,6 +673,10 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
     if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
     if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
     if (!getenv("CDL_NO_TILED")) {
+        if (mfma_wgrad_enabled()) {
+            const int rcm = cdl_mfma_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
+            if (rcm != CDL_EUNSUPPORTED) return rcm;
+        }
         const int rc = cdl_tiled_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }

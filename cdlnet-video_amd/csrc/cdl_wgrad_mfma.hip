@@ -1,0 +1,282 @@
+// Filter gradients on the matrix cores for the shapes the fused 2-D kernel does not take (any C, 2-D / 3-D,
+// stride 1 / 2, odd square planes up to 9 x 9): what autograd computes for the reference's conv / conv-transpose
+// weights (train.py:98, train3d.py:113),
+//     dw[m][c][kd][ki][kj] = alpha * sum_{n,zd,zy,zx} F[n][m][zd][zy][zx] * X[n][c][zd*sd-pd+kd][zy*s-ph+ki][zx*s-pw+kj]
+// with F the code-like operand (optionally gated by the support of another code tensor).
+//
+// Per (c, kd) group one GEMM with the PIXEL index as k:   D[tap][m] = sum_px A[tap][px] * B[px][m]
+//   A: im2col of the thin image, gathered from a bf16 hi/lo tile in LDS (lane = tap row, 8 consecutive pixels)
+//   B: the fat operand straight from global memory (lane = channel column, 8 consecutive pixels of its row)
+// split-bf16 x3 products, fp32 accumulation.  A workgroup owns a 64 x 32 tile of code pixels of one (n, zd); its 8
+// waves split the code channels (two 32-channel tiles per wave) and then the pixels; every wave writes its own
+// partial bank to the workspace and k_wgm_fold adds all partials in a fixed order: deterministic, no atomics.
+#include "cdl_common.h"
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int GLX = 64, GLY = 32;          // code-pixel tile of a workgroup
+constexpr int GNT = 512;                   // 8 waves
+constexpr int CT = 2;                      // 32-channel tiles per wave
+constexpr int KSTEPS = GLX * GLY / 16;     // 16-pixel k-steps per tile (4 per code row)
+
+// NG = number of (c, kd) groups held at once: the fat operand is loaded and split into bf16 parts ONCE per
+// k-step and multiplied against the thin tiles of all NG groups (their LDS tiles and accumulators live side by
+// side); launches loop over ceil(G / NG) group batches.
+template <int PH, int PW, int SW, int NG>
+__global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F,
+                                             const float *__restrict__ gate, const float *__restrict__ x,
+                                             float *__restrict__ part, int tilesX, int tilesY, int nct, int MP)
+{
+    constexpr int T = PH * PW, RT = (T + 31) / 32, TP = RT * 32;
+    constexpr int XH = (GLY - 1) * SW + PH, XW = (GLX - 1) * SW + PW;
+    constexpr int XE = ((XH * XW + 7) / 8) * 8;            // elements per bf16 plane (16-byte multiple)
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *xh = reinterpret_cast<__bf16 *>(smem);         // [NG][XE] hi parts of the image rows under the tile
+    __bf16 *xl = xh + NG * XE;                             // [NG][XE] lo parts
+    float *red = reinterpret_cast<float *>(smem);          // [8 waves][16][64] cross-wave sums (reuses the tiles)
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b % Dz, n = b / Dz;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int G = g.C * g.Pd;
+    const int npx = 8 / nct;                               // pixel parts (waves per channel group)
+    const int cg = wv % nct, pp = wv / nct;
+    const bool active = pp < npx;                          // 8 % nct waves idle when nct does not divide 8
+    const int kpw = KSTEPS / npx;                          // k-steps per wave
+    const size_t slab = (size_t)Dz * Hz * Wz;
+    const size_t fbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
+    const int ybase = ty * GLY * SW - g.ph, xbase = tx * GLX * SW - g.pw;
+
+    // tap of this lane's A rows (clamped into the plane for the padding rows: their outputs are never read)
+    int tki[RT], tkj[RT];
+#pragma unroll
+    for (int R = 0; R < RT; ++R) {
+        const int t = min(32 * R + l32, T - 1);
+        tki[R] = t / PW;
+        tkj[R] = t % PW;
+    }
+
+    for (int g0 = 0; g0 < G; g0 += NG) {
+        __syncthreads();                                   // previous batch's reduction has read the buffer
+#pragma unroll 1
+        for (int gi = 0; gi < NG; ++gi) {
+            const int grp = g0 + gi;
+            const int kd = grp % g.Pd, c = grp / g.Pd;
+            const int d = zd * g.sd - g.pd + kd;
+            const bool dok = grp < G && d >= 0 && d < g.D;  // uniform; a plane outside the image is a zero tile
+            const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
+            for (int i = threadIdx.x; i < XH * XW; i += GNT) {
+                const int col = i % XW, row = i / XW;
+                const int yy = ybase + row, xx = xbase + col;
+                const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
+                const __bf16 hh = (__bf16)v;
+                xh[gi * XE + i] = hh;
+                xl[gi * XE + i] = (__bf16)(v - (float)hh);
+            }
+        }
+        __syncthreads();
+        f32x16 acc[NG][RT][CT];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int R = 0; R < RT; ++R)
+#pragma unroll
+                for (int q = 0; q < CT; ++q)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[gi][R][q][v] = 0.0f;
+        if (active) {
+#pragma unroll 1
+            for (int ks = pp * kpw; ks < (pp + 1) * kpw; ++ks) {
+                const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;       // tile-local pixels zx0 .. zx0+7 of row zy
+                const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
+                // ---- B: the fat operand, 8 consecutive pixels of this lane's channel(s); shared by all NG groups
+                bf16x8 bh[CT], bl[CT];
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    const int m = 32 * (CT * cg + q) + l32;
+                    const bool mok = m < g.M && cy < Hz;
+                    const size_t rowi = fbase + (size_t)(mok ? m : 0) * slab + (size_t)(mok ? cy : 0) * Wz;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bool ok = mok && cx0 + i < Wz;
+                        const size_t idx = rowi + (ok ? cx0 + i : 0);
+                        float v = F[idx];
+                        if (gate && gate[idx] == 0.0f) v = 0.0f;
+                        v = ok ? v : 0.0f;
+                        const __bf16 hh = (__bf16)v;
+                        bh[q][i] = hh;
+                        bl[q][i] = (__bf16)(v - (float)hh);
+                    }
+                }
+                // ---- A: im2col rows of this lane's taps, gathered from LDS, and the products
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                    for (int R = 0; R < RT; ++R) {
+                        const int o = gi * XE + (zy * SW + tki[R]) * XW + zx0 * SW + tkj[R];
+                        bf16x8 ah, al;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            ah[i] = xh[o + i * SW];
+                            al[i] = xl[o + i * SW];
+                        }
+#pragma unroll
+                        for (int q = 0; q < CT; ++q) {
+                            acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[gi][R][q], 0, 0, 0);
+                            acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[gi][R][q], 0, 0, 0);
+                            acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[gi][R][q], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        // ---- sum the pixel parts of every channel group through LDS (fixed order) and write ONE partial bank per
+        //      tile: partial[tile][grp][tap][m]; register v of tile (R, q) is tap 32R + 8(v>>2) + 4h + (v&3) of
+        //      channel 32(CT cg + q) + l32
+#pragma unroll                                             // static accumulator indices (a rolled loop sends acc to scratch)
+        for (int gi = 0; gi < NG; ++gi) {
+            if (g0 + gi >= G) continue;                    // uniform
+            float *dst = part + ((size_t)blockIdx.x * G + g0 + gi) * ((size_t)TP * MP);
+#pragma unroll
+            for (int R = 0; R < RT; ++R)
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    __syncthreads();                       // the tiles (first round) / the previous round are consumed
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) red[(wv * 16 + v) * 64 + lane] = acc[gi][R][q][v];
+                    __syncthreads();
+                    for (int o = threadIdx.x; o < nct * 1024; o += GNT) {
+                        const int cgo = o >> 10, e = o & 1023, v = e >> 6, ln = e & 63;
+                        float sum = 0.0f;
+                        for (int p2 = 0; p2 < npx; ++p2) sum += red[((p2 * nct + cgo) * 16 + v) * 64 + ln];
+                        const int tap = 32 * R + 8 * (v >> 2) + 4 * (ln >> 5) + (v & 3);
+                        const int m = 32 * (CT * cgo + q) + (ln & 31);
+                        dst[(size_t)tap * MP + m] = sum;
+                    }
+                }
+        }
+    }
+}
+
+// dw[m][grp][tap] = alpha * sum over the tiles of part[tile][grp][tap][m]; 16 outputs x 16 strided partial
+// sums per workgroup, combined in a fixed order
+__global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part, float *__restrict__ dw, float alpha,
+                                                  int nparts, int G, int M, int T, int TP, int MP)
+{
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, ps = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o, total = M * G * T;
+    float s = 0.0f;
+    if (i < total) {
+        const int tap = i % T;
+        const int r = i / T;
+        const int grp = r % G, m = r / G;
+        const size_t off = ((size_t)grp * TP + tap) * MP + m, stride = (size_t)G * TP * MP;
+        for (int t = ps; t < nparts; t += 16) s += part[(size_t)t * stride + off];
+    }
+    red[ps][o] = s;
+    __syncthreads();
+    if (ps == 0 && i < total) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][o];
+        dw[i] = alpha * v;                                  // (M, C, Pd, Ph, Pw) = [m][grp][tap]
+    }
+}
+
+struct Plan {
+    int tilesX, tilesY, nct, npx, MP, TP, ng;
+    size_t tiles, part_floats, lds;
+};
+
+bool plan_for(const cdl_geom *g, Plan *p)
+{
+    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
+    const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    const int MT = (g->M + 31) / 32;
+    p->nct = (MT + CT - 1) / CT;
+    if (p->nct > 8) return false;                          // M <= 512
+    p->npx = 8 / p->nct;
+    if (KSTEPS % p->npx) return false;
+    p->MP = p->nct * CT * 32;
+    p->TP = ((g->Ph * g->Pw + 31) / 32) * 32;
+    p->tilesX = (Wz + GLX - 1) / GLX;
+    p->tilesY = (Hz + GLY - 1) / GLY;
+    p->tiles = (size_t)g->N * Dz * p->tilesX * p->tilesY;
+    p->part_floats = p->tiles * g->C * g->Pd * p->TP * p->MP;
+    const size_t XH = (size_t)(GLY - 1) * g->sh + g->Ph, XW = (size_t)(GLX - 1) * g->sw + g->Pw;
+    p->ng = 1;                                             // groups held at once: registers (NG*RT*CT*16 <= 192) and LDS permitting
+    const int G = g->C * g->Pd, RT = p->TP / 32;
+    const size_t plane = ((XH * XW + 7) / 8) * 8 * 2 * 2;   // hi + lo bf16 planes of one group
+    if (G >= 5 && RT == 1 && 5 * plane <= 96 * 1024) p->ng = 5;
+    else if (G >= 3 && RT <= 2 && 3 * plane <= 96 * 1024) p->ng = 3;
+    p->lds = p->ng * plane;
+    if (p->lds < 8 * 16 * 64 * 4) p->lds = 8 * 16 * 64 * 4;  // the cross-wave reduction buffer reuses it
+    if (p->lds > 96 * 1024) return false;
+    if (p->tiles < 64 || p->tiles >= ((size_t)1 << 31)) return false;   // too few workgroups: the VALU kernels do better
+    if (p->part_floats > ((size_t)1 << 27)) return false;               // 512 MiB of partials: not worth it
+    return true;
+}
+
+template <int PH, int PW, int SW, int NG>
+int launch_ng(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
+              hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_wgm<PH, PW, SW, NG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_wgm<PH, PW, SW, NG><<<(unsigned)p.tiles, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int PH, int PW, int SW>
+int launch(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float alpha,
+           float *dw, float *ws, hipStream_t st)
+{
+    constexpr int RT = (PH * PW + 31) / 32;
+    int rc;
+    if (RT == 1 && p.ng == 5) rc = launch_ng<PH, PW, SW, (RT == 1 ? 5 : 1)>(g, p, F, gate, x, ws, st);
+    else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st);
+    else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st);
+    if (rc) return rc;
+    const int G = g->C * g->Pd, T = g->Ph * g->Pw, total = g->M * G * T;
+    k_wgm_fold<<<(total + 15) / 16, 256, 0, st>>>(ws, dw, alpha, (int)p.tiles, G, g->M, T, p.TP, p.MP);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g)
+{
+    Plan p;
+    return plan_for(g, &p) ? p.part_floats : 0;
+}
+
+// CDL_EUNSUPPORTED: the caller falls back to the VALU kernels
+int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                   float *ws, size_t ws_floats, void *stream)
+{
+    Plan p;
+    if (!plan_for(g, &p) || !ws || ws_floats < p.part_floats) return CDL_EUNSUPPORTED;
+#define CDL_M(P_, S_) \
+    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream))
+    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
+    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#undef CDL_M
+    return CDL_EUNSUPPORTED;
+}

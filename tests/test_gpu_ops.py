@@ -88,8 +88,12 @@ def test_synthesis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
     assert torch.equal(o.synthesis(geom, zd, wd), o.synthesis(geom, zd, wd))
 
 
+@pytest.mark.parametrize("path", ["mfma", "valu"])
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
-def test_filter_and_threshold_grads(N, C, M, sp, P, s):
+def test_filter_and_threshold_grads(N, C, M, sp, P, s, path, monkeypatch):
+    """Filter gradients through the matrix-core kernel (default where it exists: >= 64 tiles of 64 x 32 code
+    pixels; smaller launches fall through) and through the fp32 VALU kernels (CDL_MFMA_WGRAD=0)."""
+    monkeypatch.setenv("CDL_MFMA_WGRAD", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=2)
     pad = tuple(p // 2 for p in P)
@@ -98,11 +102,12 @@ def test_filter_and_threshold_grads(N, C, M, sp, P, s):
     wv = w.clone().requires_grad_(True)
     u = torch.randn(z.shape)
     (O.analysis(x, wv, s, pad) * (u * (z != 0))).sum().backward()
-    tag = f"wgrad N{N}C{C}M{M}{sp}P{P}s{s}"
-    check(tag + " gated", o.wgrad(geom, u.cuda(), x.cuda(), 1.0, gate=z.cuda()), wv.grad, 1e-5)
+    tag = f"wgrad[{path}] N{N}C{C}M{M}{sp}P{P}s{s}"
+    wtol = 2e-5 if path == "mfma" else 1e-5           # split-bf16 x3 operands (as the fused kernels) vs fp32 FMAs
+    check(tag + " gated", o.wgrad(geom, u.cuda(), x.cuda(), 1.0, gate=z.cuda()), wv.grad, wtol)
     wv.grad = None
     (O.synthesis(z, wv, s, pad) * x).sum().backward()
-    check(tag + " synth", o.wgrad(geom, z.cuda(), x.cuda(), -2.0), -2.0 * wv.grad, 1e-5)
+    check(tag + " synth", o.wgrad(geom, z.cuda(), x.cuda(), -2.0), -2.0 * wv.grad, wtol)
     # threshold gradient
     c = torch.rand(N)
     dt = torch.zeros(2, M, device="cuda")
