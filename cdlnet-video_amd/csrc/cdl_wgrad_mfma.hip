@@ -54,6 +54,8 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
     const size_t slab = (size_t)Dz * Hz * Wz;
     const size_t fbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
     const int ybase = ty * GLY * SW - g.ph, xbase = tx * GLX * SW - g.pw;
+    // 16-byte loads of the fat operand need rows that start on 16-byte boundaries (the base pointers do)
+    const bool vec4 = (Wz & 3) == 0 && ((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(gate)) & 15) == 0;
 
     // tap of this lane's A rows (clamped into the plane for the padding rows: their outputs are never read)
     int tki[RT], tkj[RT];
@@ -104,16 +106,34 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                     const int m = 32 * (CT * cg + q) + l32;
                     const bool mok = m < g.M && cy < Hz;
                     const size_t rowi = fbase + (size_t)(mok ? m : 0) * slab + (size_t)(mok ? cy : 0) * Wz;
+                    float fv[8];
+                    if (vec4 && mok && cx0 + 8 <= Wz) {            // whole 32-byte segment inside the row: two 16-byte loads
+                        const float4 a0 = *reinterpret_cast<const float4 *>(F + rowi + cx0);
+                        const float4 a1 = *reinterpret_cast<const float4 *>(F + rowi + cx0 + 4);
+                        fv[0] = a0.x; fv[1] = a0.y; fv[2] = a0.z; fv[3] = a0.w;
+                        fv[4] = a1.x; fv[5] = a1.y; fv[6] = a1.z; fv[7] = a1.w;
+                        if (gate) {
+                            const float4 g0 = *reinterpret_cast<const float4 *>(gate + rowi + cx0);
+                            const float4 g1 = *reinterpret_cast<const float4 *>(gate + rowi + cx0 + 4);
+                            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) fv[i] = gg[i] == 0.0f ? 0.0f : fv[i];
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const bool ok = mok && cx0 + i < Wz;
+                            const size_t idx = rowi + (ok ? cx0 + i : 0);
+                            float v = F[idx];
+                            if (gate && gate[idx] == 0.0f) v = 0.0f;
+                            fv[i] = ok ? v : 0.0f;
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const bool ok = mok && cx0 + i < Wz;
-                        const size_t idx = rowi + (ok ? cx0 + i : 0);
-                        float v = F[idx];
-                        if (gate && gate[idx] == 0.0f) v = 0.0f;
-                        v = ok ? v : 0.0f;
-                        const __bf16 hh = (__bf16)v;
+                        const __bf16 hh = (__bf16)fv[i];
                         bh[q][i] = hh;
-                        bl[q][i] = (__bf16)(v - (float)hh);
+                        bl[q][i] = (__bf16)(fv[i] - (float)hh);
                     }
                 }
                 // ---- A: im2col rows of this lane's taps, gathered from LDS, and the products
