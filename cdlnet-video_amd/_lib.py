@@ -47,6 +47,8 @@ SIGNATURES = {
     "cdl_synthesis_ws": [_G, _P, _P, _P, _F, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
+    "cdl_analysis_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
+    "cdl_analysis_prox_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_analysis_prox": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cdl_ista_forward": [_G, _I] + [_P] * 14 + [ctypes.c_size_t, _P],
     "cdl_ista_backward": [_G, _I] + [_P] * 26 + [ctypes.c_size_t, _P],
@@ -73,7 +75,7 @@ SIGNATURES = {
 SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
-                "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G],
+                "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G], "cdl_analysis_workspace_floats": [_G],
                 "cdl_nle_mad_scratch_floats": [_I, _I, _I, _I]}
 
 _lib = None

@@ -1,0 +1,244 @@
+// Analysis (correlation with the filter bank) on the matrix cores for the shapes the fused 2-D kernel does not
+// take: any C, 2-D / 3-D, stride 1 / 2, odd square planes up to 9 x 9 (reference F.conv2d / F.conv3d at
+// model/net.py:85,87,200,205 and their use in the reverse sweep), with cdl_analysis' epilogues:
+//     acc  = alpha * sum_k W[m][k] X[k(px)]            k = (c, kd, ki, kj) in the filter's own memory order
+//     base = zin ? (gate ? (gate != 0 ? zin : 0) : zin) : 0
+//     out  = prox(base + acc) | ST(base + acc, tau[n,m]) | base + acc
+// One GEMM D[m][px] = sum_k A[m][k] B[k][px]: A = the filter rows (prepared once per launch as bf16 hi/lo MFMA
+// fragments, resident in LDS), B = im2col of the thin image, gathered from bf16 hi/lo planes in LDS through a tap ->
+// offset table (lane = pixel column, 8 consecutive taps), split-bf16 x3 products, fp32 accumulation.  A workgroup
+// walks TPW consecutive 32 x 8 tiles of output pixels with the same weights; each of its 8 waves owns one pixel row.
+//
+// Status (round 1): correct on every shape (tests run it with CDL_MFMA_ANALYSIS=1), but its epilogue -- 16*MT
+// fat loads and stores per lane with 64-bit addresses, no overlap between tiles -- makes it slower than the VALU
+// kernel except where few channel tiles meet several image channels (cfg4: 0.30 -> 0.20 ms; cfg3 0.26 -> 0.31 ms;
+// M = 169: 0.67 -> 1.25 ms with register spills).  It is therefore the default only for C > 1 and M <= 64.
+#include "cdl_common.h"
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int ALX = 32, ALY = 8;          // output-pixel tile: 8 rows of 32 pixels, one row per wave
+constexpr int ANT = 64 * ALY;
+constexpr int TPW = 4;                    // tiles (along x) per workgroup: the weight fragments are loaded once for them
+
+// filters (M, K) with K = C*Pd*Ph*Pw -> A fragments frag[(R*KS + ks)*2 + hl][lane]: lane (row m = 32R + (lane&31),
+// h = lane>>5) holds taps k = 16ks + 8h + i (zero beyond M or K)
+__global__ void k_ana_prep(const float *__restrict__ w, uint4 *__restrict__ frags, int M, int K, int MT, int KS)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= MT * KS * 64) return;
+    const int lane = t & 63, ks = (t >> 6) % KS, R = (t >> 6) / KS;
+    const int m = 32 * R + (lane & 31), h = lane >> 5;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 16 * ks + 8 * h + i;
+        const float v = (m < M && k < K) ? w[(size_t)m * K + k] : 0.0f;
+        const __bf16 hh = (__bf16)v;
+        hi[i] = hh;
+        lo[i] = (__bf16)(v - (float)hh);
+    }
+    frags[((size_t)(R * KS + ks) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    frags[((size_t)(R * KS + ks) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+template <int PH, int PW, int SW, int MT>
+__global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restrict__ x,
+                                               const uint4 *__restrict__ frags, float alpha,
+                                               const float *__restrict__ zin, const float *__restrict__ gate,
+                                               const float *__restrict__ tau, float *__restrict__ out,
+                                               cdl_prox_args px, int tilesX, int tilesY, int KS)
+{
+    constexpr int XH = (ALY - 1) * SW + PH, XW = (ALX - 1) * SW + PW;
+    constexpr int PS = ((XH * XW + 7) / 8) * 8;            // elements per plane
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int NP = g.C * g.Pd;                             // image planes under a tile
+    uint4 *wl = reinterpret_cast<uint4 *>(smem);           // [MT][KS][2][64] weight fragments
+    int *koff = reinterpret_cast<int *>(smem + (size_t)MT * KS * 2 * 64 * 16);        // [KS*16] tap -> offset
+    __bf16 *xh = reinterpret_cast<__bf16 *>(koff + KS * 16);                          // [NP][PS] hi
+    __bf16 *xl = xh + (size_t)NP * PS;                                                // [NP][PS] lo
+    const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
+    const int K = NP * PH * PW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+
+    // once per workgroup: weight fragments and the tap table
+    for (int i = threadIdx.x; i < MT * KS * 2 * 64; i += ANT) wl[i] = frags[i];
+    for (int k = threadIdx.x; k < KS * 16; k += ANT) {
+        int o = 0;
+        if (k < K) {
+            const int kj = k % PW;
+            int r = k / PW;
+            const int ki = r % PH, p = r / PH;             // p = c * Pd + kd
+            o = p * PS + ki * XW + kj;
+        }
+        koff[k] = o;
+    }
+
+    int b = blockIdx.x;
+    const int txg = b % ((tilesX + TPW - 1) / TPW); b /= (tilesX + TPW - 1) / TPW;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b % Dz, n = b / Dz;
+    const size_t slab = (size_t)Dz * Hz * Wz;
+    const int zy = ty * ALY + wv;                          // this wave's output row
+    const int pixbase = (wv * SW) * XW + l32 * SW;
+
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int tx = txg * TPW + tt;
+        if (tx >= tilesX) break;                           // uniform
+        const int ybase = ty * ALY * SW - g.ph, xbase = tx * ALX * SW - g.pw;
+        __syncthreads();                                   // previous tile's readers are done (and the tables are in)
+        for (int p = 0; p < NP; ++p) {
+            const int kd = p % g.Pd, c = p / g.Pd;
+            const int d = zd * g.sd - g.pd + kd;
+            const bool dok = d >= 0 && d < g.D;
+            const float *xplane = x + (((size_t)n * g.C + c) * g.D + (dok ? d : 0)) * g.H * g.W;
+            for (int i = threadIdx.x; i < XH * XW; i += ANT) {
+                const int col = i % XW, row = i / XW;
+                const int yy = ybase + row, xx = xbase + col;
+                const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
+                const __bf16 hh = (__bf16)v;
+                xh[p * PS + i] = hh;
+                xl[p * PS + i] = (__bf16)(v - (float)hh);
+            }
+        }
+        __syncthreads();
+        f32x16 acc[MT];
+#pragma unroll
+        for (int R = 0; R < MT; ++R)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            const int4 o0 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h);
+            const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
+            const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bh[i] = xh[oo[i] + pixbase];
+                bl[i] = xl[oo[i] + pixbase];
+            }
+#pragma unroll
+            for (int R = 0; R < MT; ++R) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 0) * 64 + lane]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 1) * 64 + lane]);
+                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
+                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
+                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
+            }
+        }
+        // epilogue: register v of tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column l32
+        const int zx = tx * ALX + l32;
+        if (zy < Hz && zx < Wz) {
+            const size_t pix = ((size_t)zd * Hz + zy) * Wz + zx;
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = 32 * R + 8 * (v >> 2) + 4 * h + (v & 3);
+                    if (m >= g.M) continue;
+                    const size_t idx = ((size_t)n * g.M + m) * slab + pix;
+                    float base = 0.0f;
+                    if (zin) {
+                        base = zin[idx];
+                        if (gate && gate[idx] == 0.0f) base = 0.0f;
+                    }
+                    const float u = fmaf(alpha, acc[R][v], base);
+                    out[idx] = px.zp ? cdl_prox_apply(px, u, idx, n * g.M + m)
+                                     : (tau ? cdl_shrink(u, tau[n * g.M + m]) : u);
+                }
+        }
+    }
+}
+
+struct Plan {
+    int tilesX, tilesY, MT, KS;
+    size_t groups, frag_uint4, lds;
+};
+
+bool plan_for(const cdl_geom *g, Plan *p)
+{
+    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
+    const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    p->MT = (g->M + 31) / 32;
+    if (p->MT > 6) return false;                           // M <= 192
+    const int K = g->C * g->Pd * g->Ph * g->Pw;
+    p->KS = (K + 15) / 16;
+    p->tilesX = (Wz + ALX - 1) / ALX;
+    p->tilesY = (Hz + ALY - 1) / ALY;
+    p->groups = (size_t)g->N * Dz * p->tilesY * ((p->tilesX + TPW - 1) / TPW);
+    p->frag_uint4 = (size_t)p->MT * p->KS * 2 * 64;
+    const size_t XH = (size_t)(ALY - 1) * g->sh + g->Ph, XW = (size_t)(ALX - 1) * g->sw + g->Pw;
+    const size_t PS = ((XH * XW + 7) / 8) * 8;
+    p->lds = p->frag_uint4 * 16 + (size_t)p->KS * 16 * 4 + (size_t)g->C * g->Pd * PS * 2 * 2;
+    if (p->lds > 96 * 1024) return false;
+    if (p->groups < 96 || p->groups >= ((size_t)1 << 31)) return false;    // small launches: the VALU kernels do better
+    return true;
+}
+
+template <int PH, int PW, int SW, int MT>
+int launch_mt(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
+              const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_ana_m<PH, PW, SW, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_ana_m<PH, PW, SW, MT><<<(unsigned)p.groups, ANT, p.lds, st>>>(*g, x, frags, alpha, zin, gate, tau, out, px,
+                                                                  p.tilesX, p.tilesY, p.KS);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int PH, int PW, int SW>
+int launch(const cdl_geom *g, const Plan &p, const float *x, const float *w, float alpha, const float *zin,
+           const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws, hipStream_t st)
+{
+    uint4 *frags = reinterpret_cast<uint4 *>(ws);
+    const int nprep = p.MT * p.KS * 64;
+    k_ana_prep<<<(nprep + 255) / 256, 256, 0, st>>>(w, frags, g->M, g->C * g->Pd * g->Ph * g->Pw, p.MT, p.KS);
+    CDL_LAUNCH_CHECK();
+    switch (p.MT) {
+        case 1: return launch_mt<PH, PW, SW, 1>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+        case 2: return launch_mt<PH, PW, SW, 2>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+        case 3: return launch_mt<PH, PW, SW, 3>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+        case 4: return launch_mt<PH, PW, SW, 4>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+        case 5: return launch_mt<PH, PW, SW, 5>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+        default: return launch_mt<PH, PW, SW, 6>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+    }
+}
+
+}  // namespace
+
+size_t cdl_mfma_analysis_ws_floats(const cdl_geom *g)
+{
+    Plan p;
+    return plan_for(g, &p) ? p.frag_uint4 * 4 : 0;
+}
+
+// CDL_EUNSUPPORTED: the caller falls back to the VALU kernels
+int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                      const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
+                      size_t ws_floats, void *stream)
+{
+    Plan p;
+    if (!plan_for(g, &p) || !ws || ws_floats < p.frag_uint4 * 4) return CDL_EUNSUPPORTED;
+    if ((reinterpret_cast<size_t>(ws) & 15) != 0) return CDL_EUNSUPPORTED;
+#define CDL_M(P_, S_) \
+    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, x, w, alpha, zin, gate, tau, out, px, ws, S(stream))
+    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
+    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#undef CDL_M
+    return CDL_EUNSUPPORTED;
+}

@@ -110,6 +110,11 @@ size_t cdl_tiled_synthesis_ws_floats(const cdl_geom *g);
 int cdl_mfma_synthesis(const cdl_geom *g, const float *z, const float *gate, const float *w, float alpha,
                        const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream);
 size_t cdl_mfma_synthesis_ws_floats(const cdl_geom *g);
+// matrix-core analysis (cdl_analysis_mfma.hip), same convention
+int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                      const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
+                      size_t ws_floats, void *stream);
+size_t cdl_mfma_analysis_ws_floats(const cdl_geom *g);
 // matrix-core filter gradients (cdl_wgrad_mfma.hip), same convention
 int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
                    float *ws, size_t ws_floats, void *stream);

@@ -547,31 +547,69 @@ int cdl_shrink(const float *x, const float *tau, float *out, int rows, size_t pe
 }
 
 static int analysis_impl(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
-                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream);
+                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
+                         size_t ws_floats, void *stream);
+
+// the matrix-core analysis (cdl_analysis_mfma.hip) is the default only where it measured faster than the VALU
+// kernel (several image channels, at most two 32-channel tiles: the JDD shapes); CDL_MFMA_ANALYSIS=1 uses it
+// wherever it has a kernel, =0 never (read per call)
+static bool mfma_analysis_enabled(const cdl_geom *g)
+{
+    const char *e = getenv("CDL_MFMA_ANALYSIS");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return g->C > 1 && g->M <= 64;
+}
+
+size_t cdl_analysis_workspace_floats(const cdl_geom *g)
+{
+    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED") || !mfma_analysis_enabled(g)) return 0;
+    return cdl_mfma_analysis_ws_floats(g);
+}
 
 int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                  const float *gate, const float *tau, float *out, void *stream)
 {
-    return analysis_impl(g, x, w, alpha, zin, gate, tau, out, cdl_prox_args{}, stream);
+    return analysis_impl(g, x, w, alpha, zin, gate, tau, out, cdl_prox_args{}, nullptr, 0, stream);
+}
+
+int cdl_analysis_ws(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                    const float *gate, const float *tau, float *out, float *workspace, size_t workspace_floats,
+                    void *stream)
+{
+    return analysis_impl(g, x, w, alpha, zin, gate, tau, out, cdl_prox_args{}, workspace, workspace_floats, stream);
 }
 
 int cdl_analysis_prox(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                       const float *z_prev, const float *z_after, const float *lam, const float *gam1,
                       const float *gam2, float *u_out, float *out, void *stream)
 {
+    return cdl_analysis_prox_ws(g, x, w, alpha, zin, z_prev, z_after, lam, gam1, gam2, u_out, out, nullptr, 0, stream);
+}
+
+int cdl_analysis_prox_ws(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                         const float *z_prev, const float *z_after, const float *lam, const float *gam1,
+                         const float *gam2, float *u_out, float *out, float *workspace, size_t workspace_floats,
+                         void *stream)
+{
     if (!z_prev || !lam || !gam1 || (z_after && !gam2)) return CDL_EINVAL;
     if (u_out && (u_out == out || u_out == zin)) return CDL_EINVAL;
     const cdl_prox_args px{z_prev, z_after, lam, gam1, gam2, u_out};
-    return analysis_impl(g, x, w, alpha, zin, nullptr, nullptr, out, px, stream);
+    return analysis_impl(g, x, w, alpha, zin, nullptr, nullptr, out, px, workspace, workspace_floats, stream);
 }
 
 static int analysis_impl(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
-                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, void *stream)
+                         const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
+                         size_t ws_floats, void *stream)
 {
     if (!cdl_geom_ok(g) || !x || !w || !out) return CDL_EINVAL;
     if (out == zin) return CDL_EINVAL;
     if (gate && !zin) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
+        if (mfma_analysis_enabled(g)) {
+            const int rcm = cdl_mfma_analysis(g, x, w, alpha, zin, gate, tau, out, px, ws, ws_floats, stream);
+            if (rcm != CDL_EUNSUPPORTED) return rcm;
+        }
         const int rc = cdl_tiled_analysis(g, x, w, alpha, zin, gate, tau, out, px, stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }

@@ -23,6 +23,7 @@ size_t cdl_ista_scratch_floats(const cdl_geom *g)
     n = max_sz(n, cdl_wgrad_workspace_floats(g));
     n = max_sz(n, cdl_synthesis_workspace_floats(g));
     n = max_sz(n, cdl_prox_csr_scratch_floats(g));
+    n = max_sz(n, cdl_analysis_workspace_floats(g));
     return n;
 }
 
@@ -44,10 +45,12 @@ int cdl_ista_forward(const cdl_geom *g, int K, const float *yp, const float *mas
         }
         const float alpha = k == 0 ? 1.0f : -1.0f;
         if (z_prev)
-            CDL_TRY(cdl_analysis_prox(g, x, wA[k], alpha, zin, z_prev, z_after, tau + k * NM, gam1 + k * NM,
-                                      gam2 ? gam2 + k * NM : nullptr, u ? u[k] : nullptr, z[k], stream));
+            CDL_TRY(cdl_analysis_prox_ws(g, x, wA[k], alpha, zin, z_prev, z_after, tau + k * NM, gam1 + k * NM,
+                                         gam2 ? gam2 + k * NM : nullptr, u ? u[k] : nullptr, z[k], scratch,
+                                         scratch_floats, stream));
         else
-            CDL_TRY(cdl_analysis(g, x, wA[k], alpha, zin, nullptr, tau + k * NM, z[k], stream));
+            CDL_TRY(cdl_analysis_ws(g, x, wA[k], alpha, zin, nullptr, tau + k * NM, z[k], scratch, scratch_floats,
+                                    stream));
     }
     return cdl_synthesis_ws(g, z[K - 1], nullptr, wB[0], 1.0f, nullptr, nullptr, xp, scratch, scratch_floats, stream);
 }
@@ -72,7 +75,7 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
     float *gk = gbuf0, *other = gbuf1;
     if (g_xp) {
         CDL_TRY(cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], scratch, scratch_floats, stream));
-        CDL_TRY(cdl_analysis(g, g_xp, wB[0], 1.0f, g_z, nullptr, nullptr, gk, stream));     // B_0^T g_xp (+ g_z)
+        CDL_TRY(cdl_analysis_ws(g, g_xp, wB[0], 1.0f, g_z, nullptr, nullptr, gk, scratch, scratch_floats, stream));   // B_0^T g_xp (+ g_z)
     } else {
         hipError_t e = hipMemsetAsync(dB[0], 0, flen * sizeof(float), S(stream));
         if (e != hipSuccess) return -(int)e;
@@ -97,7 +100,7 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
         CDL_TRY(cdl_synthesis_ws(g, gk, gate, wA[k], -1.0f, mask, nullptr, q, scratch, scratch_floats, stream));
         CDL_TRY(cdl_wgrad(g, gk, gate, r[k - 1], -1.0f, dA[k], scratch, scratch_floats, stream));
         CDL_TRY(cdl_wgrad(g, z[k - 1], nullptr, q, 1.0f, dB[k], scratch, scratch_floats, stream));
-        CDL_TRY(cdl_analysis(g, q, wB[k], 1.0f, gk, gate, nullptr, other, stream));
+        CDL_TRY(cdl_analysis_ws(g, q, wB[k], 1.0f, gk, gate, nullptr, other, scratch, scratch_floats, stream));
         float *t = gk;
         gk = other;
         other = t;

@@ -194,9 +194,11 @@ def analysis(g: Geometry, x, w, alpha=1.0, zin=None, gate=None, tau=None, out=No
     if out is None:
         out = torch.empty(g.code_shape(), device=x.device, dtype=torch.float32)
     gs = g.c_struct()
-    rc = _lib.lib().cdl_analysis(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin),
-                                 _ptr(gate), _ptr(tau), _ptr(out), _stream())
-    _lib.check(rc, "cdl_analysis")
+    n = int(_lib.lib().cdl_analysis_workspace_floats(ctypes.byref(gs)))
+    ws = _scratch(x.device, n) if n else None
+    rc = _lib.lib().cdl_analysis_ws(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin),
+                                    _ptr(gate), _ptr(tau), _ptr(out), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_analysis_ws")
     return out
 
 
@@ -288,10 +290,12 @@ def analysis_prox(g: Geometry, x, w, alpha, zin, z_prev, lam, gam1, z_after=None
     if out is None:
         out = torch.empty(g.code_shape(), device=x.device, dtype=torch.float32)
     gs = g.c_struct()
-    rc = _lib.lib().cdl_analysis_prox(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin), _ptr(z_prev),
-                                      _ptr(z_after), _ptr(_dev(lam, "lam")), _ptr(_dev(gam1, "gam1")),
-                                      _ptr(_opt(gam2, "gam2")), _ptr(u_out), _ptr(out), _stream())
-    _lib.check(rc, "cdl_analysis_prox")
+    n = int(_lib.lib().cdl_analysis_workspace_floats(ctypes.byref(gs)))
+    ws = _scratch(x.device, n) if n else None
+    rc = _lib.lib().cdl_analysis_prox_ws(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin), _ptr(z_prev),
+                                         _ptr(z_after), _ptr(_dev(lam, "lam")), _ptr(_dev(gam1, "gam1")),
+                                         _ptr(_opt(gam2, "gam2")), _ptr(u_out), _ptr(out), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_analysis_prox_ws")
     return out
 
 

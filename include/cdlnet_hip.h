@@ -84,6 +84,13 @@ int cdl_shrink(const float *x, const float *tau /*rows*/, float *out, int rows, 
 int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha,
                  const float *zin /*nullable*/, const float *gate /*nullable*/,
                  const float *tau /*N*M, nullable*/, float *out, void *stream);
+/* cdl_analysis with scratch (cdl_analysis_workspace_floats(g) floats, 0 when no kernel wants it): lets the
+ * matrix-core kernel of the shape-generic path stage its prepared filter fragments.  workspace == NULL: VALU. */
+int cdl_analysis_ws(const cdl_geom *g, const float *x, const float *w, float alpha,
+                    const float *zin /*nullable*/, const float *gate /*nullable*/,
+                    const float *tau /*N*M, nullable*/, float *out, float *workspace, size_t workspace_floats,
+                    void *stream);
+size_t cdl_analysis_workspace_floats(const cdl_geom *g);
 
 /* ---- synthesis half: F.conv_transpose2d/3d at net.py:87,90,205,210 and gabor.py:64 ----------
  *   v   = alpha * corrT( gate ? [gate!=0]*z : z ; w )   z fat, v thin, output_padding = s-1
@@ -137,6 +144,11 @@ int cdl_analysis_prox(const cdl_geom *g, const float *x, const float *w, float a
                       const float *zin /*nullable*/, const float *z_prev, const float *z_after /*nullable*/,
                       const float *lam, const float *gam1, const float *gam2 /*nullable*/,
                       float *u_out /*nullable*/, float *out, void *stream);
+int cdl_analysis_prox_ws(const cdl_geom *g, const float *x, const float *w, float alpha,
+                         const float *zin /*nullable*/, const float *z_prev, const float *z_after /*nullable*/,
+                         const float *lam, const float *gam1, const float *gam2 /*nullable*/,
+                         float *u_out /*nullable*/, float *out, float *workspace, size_t workspace_floats,
+                         void *stream);
 
 /* Reverse of cdl_prox_csr as autograd differentiates the reference expression (sign() has zero
  * gradient): gu = dL/du (may alias gz); gz_prev / gz_after (nullable) are ACCUMULATED into, because a
