@@ -238,31 +238,45 @@ __global__ __launch_bounds__(256) void k_wgrad(cdl_geom g, const float *__restri
 // threshold gradient, stage 1: s[n,m] = -sum_pix sign(zout) * g over the support of zout.
 __global__ __launch_bounds__(256) void k_tau_partial(const float *__restrict__ gup,
                                                      const float *__restrict__ zout,
-                                                     float *__restrict__ s, size_t per_m)
+                                                     float *__restrict__ s, size_t per_m, int S)
 {
+    // one workgroup per (row, split): the N*M rows alone are too few workgroups for a batch of a few clips, and
+    // 4 independent accumulators keep 8 loads in flight per thread
     __shared__ float red[4];
-    const size_t base = (size_t)blockIdx.x * per_m;
-    float acc = 0.0f;
-    for (size_t i = threadIdx.x; i < per_m; i += 256) {
-        float zv = zout[base + i];
-        float gv = gup[base + i];
-        acc += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+    const int row = blockIdx.x / S, sp = blockIdx.x % S;
+    const size_t chunk = (per_m + S - 1) / S;
+    const size_t lo = (size_t)sp * chunk, hi = lo + chunk < per_m ? lo + chunk : per_m;
+    const size_t base = (size_t)row * per_m;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float zv = zout[base + i + u * 256], gv = gup[base + i + u * 256];
+            a[u] += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+        }
     }
+    for (; i < hi; i += 256) {
+        const float zv = zout[base + i], gv = gup[base + i];
+        a[0] += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+    }
+    float acc = (a[0] + a[1]) + (a[2] + a[3]);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (threadIdx.x % 64 == 0) red[threadIdx.x / 64] = acc;
     __syncthreads();
     if (threadIdx.x == 0) s[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// stage 2: dt0[m] = sum_n s[n,m]; dt1[m] = sum_n c[n] s[n,m]
+// stage 2: dt0[m] = sum_n sum_splits s[n,m,.]; dt1[m] = sum_n c[n] * (sum_splits s[n,m,.])
 __global__ void k_tau_final(const float *__restrict__ s, const float *__restrict__ c,
-                            float *__restrict__ dt0, float *__restrict__ dt1, int N, int M)
+                            float *__restrict__ dt0, float *__restrict__ dt1, int N, int M, int S)
 {
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float a0 = 0.0f, a1 = 0.0f;
     for (int n = 0; n < N; ++n) {
-        float v = s[n * M + m];
+        float v = 0.0f;
+        for (int k = 0; k < S; ++k) v += s[(size_t)(n * M + m) * S + k];
         a0 += v;
         if (c) a1 = fmaf(c[n], v, a1);
     }
@@ -729,9 +743,16 @@ int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const f
 {
     if (!cdl_geom_ok(g) || !gup || !zout || !dt0 || !dt1 || !scratch) return CDL_EINVAL;
     size_t per_m = (size_t)(g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
-    k_tau_partial<<<(unsigned)(g->N * g->M), 256, 0, S(stream)>>>(gup, zout, scratch, per_m);
+    // splits per (n, m) row: about 2048 workgroups of at least 4096 elements, at most CDL_TAU_SPLITS (the scratch)
+    const int rows = g->N * g->M;
+    int Sp = (2048 + rows - 1) / rows;
+    const size_t most = (per_m + 4095) / 4096;
+    if ((size_t)Sp > most) Sp = (int)most;
+    if (Sp > CDL_TAU_SPLITS) Sp = CDL_TAU_SPLITS;
+    if (Sp < 1) Sp = 1;
+    k_tau_partial<<<(unsigned)(rows * Sp), 256, 0, S(stream)>>>(gup, zout, scratch, per_m, Sp);
     CDL_LAUNCH_CHECK();
-    k_tau_final<<<(g->M + 63) / 64, 64, 0, S(stream)>>>(scratch, c, dt0, dt1, g->N, g->M);
+    k_tau_final<<<(g->M + 63) / 64, 64, 0, S(stream)>>>(scratch, c, dt0, dt1, g->N, g->M, Sp);
     CDL_LAUNCH_CHECK();
     return 0;
 }

@@ -19,7 +19,7 @@ extern "C" {
 size_t cdl_ista_scratch_floats(const cdl_geom *g)
 {
     if (!cdl_geom_ok(g)) return 0;
-    size_t n = (size_t)g->N * g->M;                              // cdl_tau_grad
+    size_t n = (size_t)CDL_TAU_SPLITS * g->N * g->M;             // cdl_tau_grad
     n = max_sz(n, cdl_wgrad_workspace_floats(g));
     n = max_sz(n, cdl_synthesis_workspace_floats(g));
     n = max_sz(n, cdl_prox_csr_scratch_floats(g));

@@ -248,7 +248,7 @@ def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):
 def tau_grad(g: Geometry, gup, zout, c, dt_k):
     """Writes the (2,M) slice `dt_k` of the threshold gradient for one iteration."""
     gup, zout, c = _dev(gup, "g"), _dev(zout, "zout"), _opt(c, "c")
-    scratch = torch.empty(g.N * g.M, device=gup.device, dtype=torch.float32)
+    scratch = torch.empty(16 * g.N * g.M, device=gup.device, dtype=torch.float32)      # CDL_TAU_SPLITS * N * M
     assert dt_k.is_contiguous() and dt_k.numel() == 2 * g.M
     gs = g.c_struct()
     base = dt_k.data_ptr()

@@ -121,9 +121,11 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g);
 
 /* Threshold gradients of one iteration: with du = [zout!=0]*g,
  *   dt0[m] = -sum_{n,pix} sign(zout)*du,   dt1[m] = -sum_n c[n] * sum_pix sign(zout)*du
- * (c NULL -> dt1 = 0).  scratch: N*M floats. dt0/dt1 are overwritten. */
+ * (c NULL -> dt1 = 0).  scratch: CDL_TAU_SPLITS*N*M floats (rows are split over workgroups and folded in a fixed
+ * order). dt0/dt1 are overwritten. */
+#define CDL_TAU_SPLITS 16
 int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c /*N, nullable*/,
-                 float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*N*M*/, void *stream);
+                 float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*CDL_TAU_SPLITS*N*M*/, void *stream);
 
 /* ---- CSR temporal variants --------------------------------------
  * prox_CSR / prox_CSR_f2 of model/net.py:229-262, the shrinkage that CDLNet_CSR.forward
