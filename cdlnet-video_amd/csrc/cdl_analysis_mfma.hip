@@ -9,10 +9,9 @@
 // offset table (lane = pixel column, 8 consecutive taps), split-bf16 x3 products, fp32 accumulation.  A workgroup
 // walks TPW consecutive 32 x 8 tiles of output pixels with the same weights; each of its 8 waves owns one pixel row.
 //
-// Status (round 1): correct on every shape (tests run it with CDL_MFMA_ANALYSIS=1), but its epilogue -- 16*MT
-// fat loads and stores per lane with 64-bit addresses, no overlap between tiles -- makes it slower than the VALU
-// kernel except where few channel tiles meet several image channels (cfg4: 0.30 -> 0.20 ms; cfg3 0.26 -> 0.31 ms;
-// M = 169: 0.67 -> 1.25 ms with register spills).  It is therefore the default only for C > 1 and M <= 64.
+// The epilogue goes through LDS one 32-channel tile at a time (a first version applied it straight from the
+// accumulator registers: 16*MT unrolled fat accesses with 64-bit addresses per lane, 1.25 ms and scratch spills at
+// M = 169 against 0.67 ms for the VALU kernel).
 #include "cdl_common.h"
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
@@ -47,7 +46,7 @@ __global__ void k_ana_prep(const float *__restrict__ w, uint4 *__restrict__ frag
     frags[((size_t)(R * KS + ks) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
-template <int PH, int PW, int SW, int MT>
+template <int PH, int PW, int SW, int MT, bool PROX>
 __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restrict__ x,
                                                const uint4 *__restrict__ frags, float alpha,
                                                const float *__restrict__ zin, const float *__restrict__ gate,
@@ -62,6 +61,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     int *koff = reinterpret_cast<int *>(smem + (size_t)MT * KS * 2 * 64 * 16);        // [KS*16] tap -> offset
     __bf16 *xh = reinterpret_cast<__bf16 *>(koff + KS * 16);                          // [NP][PS] hi
     __bf16 *xl = xh + (size_t)NP * PS;                                                // [NP][PS] lo
+    float *stage = reinterpret_cast<float *>(xh);          // [32][ALX*ALY] epilogue staging, reuses the planes (32 KB)
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
     const int K = NP * PH * PW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     const int ty = b % tilesY; b /= tilesY;
     const int zd = b % Dz, n = b / Dz;
     const size_t slab = (size_t)Dz * Hz * Wz;
-    const int zy = ty * ALY + wv;                          // this wave's output row
     const int pixbase = (wv * SW) * XW + l32 * SW;
 
     for (int tt = 0; tt < TPW; ++tt) {
@@ -133,26 +132,50 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                 acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
             }
         }
-        // epilogue: register v of tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column l32
-        const int zx = tx * ALX + l32;
-        if (zy < Hz && zx < Wz) {
-            const size_t pix = ((size_t)zd * Hz + zy) * Wz + zx;
+        // epilogue through LDS, one 32-channel accumulator tile at a time: the waves park tile R as [channel][pixel]
+        // (register v is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column l32 of row wv), then all 512 threads walk
+        // the 32 x 256 values with a rolled loop -- 32-bit index arithmetic, pixel-contiguous fat accesses, and none of
+        // the 16*MT-fold unrolled 64-bit addressing that sent the M = 169 variant to scratch
+        const size_t nbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
 #pragma unroll
-            for (int R = 0; R < MT; ++R)
+        for (int R = 0; R < MT; ++R) {
+            __syncthreads();                               // image planes (first round) / previous tile consumed
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = 32 * R + 8 * (v >> 2) + 4 * h + (v & 3);
-                    if (m >= g.M) continue;
-                    const size_t idx = ((size_t)n * g.M + m) * slab + pix;
-                    float base = 0.0f;
-                    if (zin) {
-                        base = zin[idx];
-                        if (gate && gate[idx] == 0.0f) base = 0.0f;
-                    }
-                    const float u = fmaf(alpha, acc[R][v], base);
-                    out[idx] = px.zp ? cdl_prox_apply(px, u, idx, n * g.M + m)
-                                     : (tau ? cdl_shrink(u, tau[n * g.M + m]) : u);
+            for (int v = 0; v < 16; ++v)
+                stage[(8 * (v >> 2) + 4 * h + (v & 3)) * (ALX * ALY) + wv * ALX + l32] = acc[R][v];
+            __syncthreads();
+            // 16 values per thread in two batches of 8 whose loads are issued together (predicated, not branched:
+            // with one tile per CU nothing else hides their latency); 32-bit offsets inside the sample's block
+            constexpr int NB = 8;
+            const float *zin_n = zin ? zin + nbase : nullptr;
+            const float *gate_n = (zin && gate) ? gate + nbase : nullptr;
+            float *out_n = out + nbase;
+#pragma unroll 1
+            for (int j0 = 0; j0 < 32 * ALX * ALY / ANT; j0 += NB) {
+                float bv[NB], gv[NB];
+                int ix[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = threadIdx.x + (j0 + j) * ANT;
+                    const int ch = e / (ALX * ALY), pxl = e % (ALX * ALY);
+                    const int m = 32 * R + ch, oy = ty * ALY + pxl / ALX, ox = tx * ALX + pxl % ALX;
+                    const bool ok = m < g.M && oy < Hz && ox < Wz;
+                    ix[j] = ok ? m * (int)slab + oy * Wz + ox : -1;
+                    bv[j] = zin_n ? zin_n[ok ? ix[j] : 0] : 0.0f;
+                    gv[j] = gate_n ? gate_n[ok ? ix[j] : 0] : 1.0f;
                 }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = threadIdx.x + (j0 + j) * ANT;
+                    const int m = min(32 * R + e / (ALX * ALY), g.M - 1);
+                    const float base = gv[j] == 0.0f ? 0.0f : bv[j];
+                    const float u = fmaf(alpha, stage[e], base);
+                    const int row = n * g.M + m;
+                    if (ix[j] >= 0)
+                        out_n[ix[j]] = PROX ? cdl_prox_apply(px, u, nbase + ix[j], row)
+                                            : (tau ? cdl_shrink(u, tau[row]) : u);
+                }
+            }
         }
     }
 }
@@ -170,6 +193,7 @@ bool plan_for(const cdl_geom *g, Plan *p)
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     p->MT = (g->M + 31) / 32;
     if (p->MT > 6) return false;                           // M <= 192
+    if ((size_t)g->M * Dz * Hz * Wz >= ((size_t)1 << 31)) return false;   // 32-bit offsets inside one sample's code block
     const int K = g->C * g->Pd * g->Ph * g->Pw;
     p->KS = (K + 15) / 16;
     p->tilesX = (Wz + ALX - 1) / ALX;
@@ -178,27 +202,37 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->frag_uint4 = (size_t)p->MT * p->KS * 2 * 64;
     const size_t XH = (size_t)(ALY - 1) * g->sh + g->Ph, XW = (size_t)(ALX - 1) * g->sw + g->Pw;
     const size_t PS = ((XH * XW + 7) / 8) * 8;
-    p->lds = p->frag_uint4 * 16 + (size_t)p->KS * 16 * 4 + (size_t)g->C * g->Pd * PS * 2 * 2;
+    size_t planes = (size_t)g->C * g->Pd * PS * 2 * 2;
+    if (planes < 32 * ALX * ALY * 4) planes = 32 * ALX * ALY * 4;          // the epilogue staging reuses them
+    p->lds = p->frag_uint4 * 16 + (size_t)p->KS * 16 * 4 + planes;
     if (p->lds > 96 * 1024) return false;
     if (p->groups < 96 || p->groups >= ((size_t)1 << 31)) return false;    // small launches: the VALU kernels do better
     return true;
+}
+
+template <int PH, int PW, int SW, int MT, bool PROX>
+int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
+               const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_ana_m<PH, PW, SW, MT, PROX>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_ana_m<PH, PW, SW, MT, PROX><<<(unsigned)p.groups, ANT, p.lds, st>>>(*g, x, frags, alpha, zin, gate, tau, out, px,
+                                                                        p.tilesX, p.tilesY, p.KS);
+    CDL_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int PH, int PW, int SW, int MT>
 int launch_mt(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
               const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_ana_m<PH, PW, SW, MT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
-    k_ana_m<PH, PW, SW, MT><<<(unsigned)p.groups, ANT, p.lds, st>>>(*g, x, frags, alpha, zin, gate, tau, out, px,
-                                                                  p.tilesX, p.tilesY, p.KS);
-    CDL_LAUNCH_CHECK();
-    return 0;
+    if (px.zp) return launch_mtp<PH, PW, SW, MT, true>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+    return launch_mtp<PH, PW, SW, MT, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
 }
 
 template <int PH, int PW, int SW>
