@@ -58,7 +58,7 @@ __global__ void k_synth_prep(const float *__restrict__ w, uint4 *__restrict__ fr
 }
 
 // ------------------------------------------------------------------------------------------
-template <int PH, int PW, int SW>
+template <int PH, int PW, int SW, int KSM>
 __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__restrict__ z,
                                                  const float *__restrict__ gate, const uint4 *__restrict__ frags,
                                                  float *__restrict__ patches, int tilesX, int tilesY, int KS)
@@ -81,6 +81,35 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
     const int cx = tx * TCX + c32;
     const int nfr = RT * KS * 2 * 64;                                          // uint4 fragments per group
 
+    // KSM > 0: the code values of this wave's pixel row are loaded and split ONCE (KS <= KSM k-steps in registers) and
+    // reused by every (c, kd) group; KSM == 0 (many code channels): reloaded per group
+    const int blk = wv;                                     // code row of this wave's block inside the tile
+    const int cy = ty * TCY + blk;
+    const bool ok = cy < Hz && cx < Wz;
+    const size_t poff = zbase + (size_t)(ok ? cy : 0) * Wz + (ok ? cx : 0);
+    bf16x8 cbh[KSM > 0 ? KSM : 1], cbl[KSM > 0 ? KSM : 1];
+    if (KSM > 0) {
+#pragma unroll
+        for (int q = 0; q < KSM; ++q) {
+            float zv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = 16 * q + 8 * h + i;
+                const bool live = ok && m < g.M;
+                const size_t idx = poff + (size_t)(live ? m : 0) * slab;
+                float v = z[idx];
+                if (gate && gate[idx] == 0.0f) v = 0.0f;
+                zv[i] = live ? v : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const __bf16 hh = (__bf16)zv[i];
+                cbh[q][i] = hh;
+                cbl[q][i] = (__bf16)(zv[i] - (float)hh);
+            }
+        }
+    }
+
     for (int grp = 0; grp < G; ++grp) {
         const int kd = grp % g.Pd;
         const int d = zd * g.sd - g.pd + kd;
@@ -89,15 +118,25 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
         for (int i = threadIdx.x; i < nfr; i += SNT) wl[i] = frags[(size_t)grp * nfr + i];
         __syncthreads();
         {
-            const int blk = wv;                             // code row of this wave's block inside the tile
-            const int cy = ty * TCY + blk;
-            const bool ok = cy < Hz && cx < Wz;
-            const size_t poff = zbase + (size_t)(ok ? cy : 0) * Wz + (ok ? cx : 0);
             f32x16 acc[RT];
 #pragma unroll
             for (int R = 0; R < RT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+            if (KSM > 0) {
+#pragma unroll
+                for (int q = 0; q < KSM; ++q) {
+                    if (q >= KS) break;
+#pragma unroll
+                    for (int R = 0; R < RT; ++R) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + q) * 2 + 0) * 64 + lane]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + q) * 2 + 1) * 64 + lane]);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cbh[q], acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cbl[q], acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cbh[q], acc[R], 0, 0, 0);
+                    }
+                }
+            } else
             for (int ks0 = 0; ks0 < KS; ks0 += KSC) {
                 float zv[KSC][8];
 #pragma unroll
@@ -239,12 +278,18 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
     CDL_LAUNCH_CHECK();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW, 0>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW, 4>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    k_synth_m<PH, PW, SW><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
+    if (p.KS <= 4 && g->C * g->Pd > 1)       // several groups share the code values: keep their fragments in registers
+        k_synth_m<PH, PW, SW, 4><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
+    else
+        k_synth_m<PH, PW, SW, 0><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
     CDL_LAUNCH_CHECK();
     dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
     k_synth_assemble<PH, PW, SW><<<grid, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
