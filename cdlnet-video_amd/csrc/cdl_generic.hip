@@ -564,15 +564,14 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
                          const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
                          size_t ws_floats, void *stream);
 
-// the matrix-core analysis (cdl_analysis_mfma.hip) is the default where it measured faster than the VALU kernel:
-// at most two 32-channel tiles (cfg3 0.26 -> 0.21 ms, cfg4 0.30 -> 0.13 ms per launch; at M = 169 its six epilogue
-// rounds per tile lose, 0.67 -> 0.90 ms); CDL_MFMA_ANALYSIS=1 uses it wherever it has a kernel, =0 never (per call)
+// the matrix-core analysis (cdl_analysis_mfma.hip) is the default wherever it has a kernel and the launch is large
+// enough; CDL_MFMA_ANALYSIS=0 selects the VALU kernels (read per call)
 static bool mfma_analysis_enabled(const cdl_geom *g)
 {
     const char *e = getenv("CDL_MFMA_ANALYSIS");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return g->M <= 64;
+    return true;
 }
 
 size_t cdl_analysis_workspace_floats(const cdl_geom *g)
