@@ -47,6 +47,7 @@ SIGNATURES = {
     "cdl_synthesis_ws": [_G, _P, _P, _P, _F, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
+    "cdl_tau_grad_gate": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_analysis_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_analysis_prox_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_analysis_prox": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void k_wgrad(cdl_geom g, const float *__restri
 
 // ------------------------------------------------------------------------------------------
 // threshold gradient, stage 1: s[n,m] = -sum_pix sign(zout) * g over the support of zout.
-__global__ __launch_bounds__(256) void k_tau_partial(const float *__restrict__ gup,
+template <bool GATE_INPLACE>
+__global__ __launch_bounds__(256) void k_tau_partial(float *__restrict__ gup,
                                                      const float *__restrict__ zout,
                                                      float *__restrict__ s, size_t per_m, int S)
 {
@@ -254,11 +255,13 @@ __global__ __launch_bounds__(256) void k_tau_partial(const float *__restrict__ g
         for (int u = 0; u < 4; ++u) {
             const float zv = zout[base + i + u * 256], gv = gup[base + i + u * 256];
             a[u] += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+            if (GATE_INPLACE && zv == 0.0f && gv != 0.0f) gup[base + i + u * 256] = 0.0f;
         }
     }
     for (; i < hi; i += 256) {
         const float zv = zout[base + i], gv = gup[base + i];
         a[0] += zv > 0.0f ? -gv : (zv < 0.0f ? gv : 0.0f);
+        if (GATE_INPLACE && zv == 0.0f && gv != 0.0f) gup[base + i] = 0.0f;
     }
     float acc = (a[0] + a[1]) + (a[2] + a[3]);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -737,8 +740,8 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
     return 0;
 }
 
-int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c, float *dt0,
-                 float *dt1, float *scratch, void *stream)
+static int tau_grad_impl(const cdl_geom *g, float *gup, const float *zout, const float *c, float *dt0, float *dt1,
+                         float *scratch, bool gate_inplace, void *stream)
 {
     if (!cdl_geom_ok(g) || !gup || !zout || !dt0 || !dt1 || !scratch) return CDL_EINVAL;
     size_t per_m = (size_t)(g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
@@ -749,11 +752,26 @@ int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const f
     if ((size_t)Sp > most) Sp = (int)most;
     if (Sp > CDL_TAU_SPLITS) Sp = CDL_TAU_SPLITS;
     if (Sp < 1) Sp = 1;
-    k_tau_partial<<<(unsigned)(rows * Sp), 256, 0, S(stream)>>>(gup, zout, scratch, per_m, Sp);
+    if (gate_inplace)
+        k_tau_partial<true><<<(unsigned)(rows * Sp), 256, 0, S(stream)>>>(gup, zout, scratch, per_m, Sp);
+    else
+        k_tau_partial<false><<<(unsigned)(rows * Sp), 256, 0, S(stream)>>>(gup, zout, scratch, per_m, Sp);
     CDL_LAUNCH_CHECK();
     k_tau_final<<<(g->M + 63) / 64, 64, 0, S(stream)>>>(scratch, c, dt0, dt1, g->N, g->M, Sp);
     CDL_LAUNCH_CHECK();
     return 0;
+}
+
+int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c, float *dt0,
+                 float *dt1, float *scratch, void *stream)
+{
+    return tau_grad_impl(g, const_cast<float *>(gup), zout, c, dt0, dt1, scratch, false, stream);
+}
+
+int cdl_tau_grad_gate(const cdl_geom *g, float *gup, const float *zout, const float *c, float *dt0, float *dt1,
+                      float *scratch, void *stream)
+{
+    return tau_grad_impl(g, gup, zout, c, dt0, dt1, scratch, true, stream);
 }
 
 int cdl_project_filters(float *w, int nfilters, int flen, void *stream)

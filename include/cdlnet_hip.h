@@ -126,6 +126,10 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g);
 #define CDL_TAU_SPLITS 16
 int cdl_tau_grad(const cdl_geom *g, const float *gup, const float *zout, const float *c /*N, nullable*/,
                  float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*CDL_TAU_SPLITS*N*M*/, void *stream);
+/* Same, and gup is gated IN PLACE (gup[i] = 0 where zout[i] == 0) in the same pass: the reverse sweep's three
+ * consumers of the gated gradient then need no gate (one fat read each less). */
+int cdl_tau_grad_gate(const cdl_geom *g, float *gup /*inout*/, const float *zout, const float *c /*N, nullable*/,
+                      float *dt0 /*M*/, float *dt1 /*M*/, float *scratch /*CDL_TAU_SPLITS*N*M*/, void *stream);
 
 /* ---- CSR temporal variants --------------------------------------
  * prox_CSR / prox_CSR_f2 of model/net.py:229-262, the shrinkage that CDLNet_CSR.forward
