@@ -47,5 +47,18 @@ def csr_inference_v2(net, frames, sigma=None, mask=1):
     codes = [None] * (T + 2)
     for t in range(T):
         _, codes[t + 1] = net(frames[t], codes[t], None, _sigma_at(sigma, t), mask=_mask_at(mask, t))
-    return [net(frames[t], codes[t], codes[t + 1], _sigma_at(sigma, t), mask=_mask_at(mask, t))[0]
-            for t in range(T)]
+    # second pass: frame t only needs recorded codes, so frames 1..T-1 (both neighbours given) go through the
+    # network as ONE batch -- the samples of a batch are independent in every kernel, so the result per frame is
+    # what the reference's frame-by-frame loop computes; frame 0 (no previous code) takes the other branch alone
+    out = [net(frames[0], None, codes[1], _sigma_at(sigma, 0), mask=_mask_at(mask, 0))[0]]
+    if T > 1:
+        same_sigma = not isinstance(sigma, (list, tuple))
+        same_mask = not isinstance(mask, (list, tuple))
+        if same_sigma and same_mask and not torch.is_tensor(sigma) and not torch.is_tensor(mask):
+            B = frames[0].shape[0]
+            xb, _ = net(torch.cat(list(frames[1:])), torch.cat(codes[1:T]), torch.cat(codes[2:T + 1]), sigma, mask=mask)
+            out.extend(xb[i * B:(i + 1) * B] for i in range(T - 1))
+        else:
+            out.extend(net(frames[t], codes[t], codes[t + 1], _sigma_at(sigma, t), mask=_mask_at(mask, t))[0]
+                       for t in range(1, T))
+    return out
