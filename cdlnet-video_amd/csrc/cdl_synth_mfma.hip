@@ -61,13 +61,14 @@ __global__ void k_synth_prep(const float *__restrict__ w, uint4 *__restrict__ fr
 template <int PH, int PW, int SW, int KSM>
 __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__restrict__ z,
                                                  const float *__restrict__ gate, const uint4 *__restrict__ frags,
-                                                 float *__restrict__ patches, int tilesX, int tilesY, int KS)
+                                                 float *__restrict__ patches, int tilesX, int tilesY, int KS, int KCH)
 {
     constexpr int T = PH * PW, RT = (T + 31) / 32;
     constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
     extern __shared__ __align__(16) unsigned char smem[];
     float *col = reinterpret_cast<float *>(smem);                              // [RT*32][TCX*TCY]
-    uint4 *wl = reinterpret_cast<uint4 *>(smem + (size_t)RT * 32 * TCX * TCY * 4);   // [RT][KS][2][64]
+    uint4 *wl = reinterpret_cast<uint4 *>(smem + (size_t)RT * 32 * TCX * TCY * 4);   // [RT][KCH][2][64]: KCH k-steps of
+                                                            // weight fragments at a time (all KS when they fit)
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
     int b = blockIdx.x;
     const int tx = b % tilesX; b /= tilesX;
@@ -114,30 +115,34 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
         const int kd = grp % g.Pd;
         const int d = zd * g.sd - g.pd + kd;
         if (d < 0 || d >= g.D) continue;                    // uniform: this depth tap falls outside the image
-        __syncthreads();                                    // previous group's gather has read col
-        for (int i = threadIdx.x; i < nfr; i += SNT) wl[i] = frags[(size_t)grp * nfr + i];
-        __syncthreads();
-        {
-            f32x16 acc[RT];
+        f32x16 acc[RT];
 #pragma unroll
-            for (int R = 0; R < RT; ++R)
+        for (int R = 0; R < RT; ++R)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-            if (KSM > 0) {
+            for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+        for (int kc0 = 0; kc0 < KS; kc0 += KCH) {           // weight fragments of KCH k-steps at a time
+            const int kcn = min(KCH, KS - kc0);
+            __syncthreads();                                // previous chunk's / group's readers are done
+            for (int i = threadIdx.x; i < RT * kcn * 2 * 64; i += SNT) {
+                const int R = i / (kcn * 2 * 64), rem = i % (kcn * 2 * 64);
+                wl[(size_t)R * KCH * 2 * 64 + rem] = frags[(size_t)grp * nfr + ((size_t)R * KS + kc0) * 2 * 64 + rem];
+            }
+            __syncthreads();
+            if (KSM > 0) {                                  // KS <= KSM: one chunk, code fragments from registers
 #pragma unroll
                 for (int q = 0; q < KSM; ++q) {
                     if (q >= KS) break;
 #pragma unroll
                     for (int R = 0; R < RT; ++R) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + q) * 2 + 0) * 64 + lane]);
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + q) * 2 + 1) * 64 + lane]);
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KCH + q) * 2 + 0) * 64 + lane]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KCH + q) * 2 + 1) * 64 + lane]);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, cbh[q], acc[R], 0, 0, 0);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cbl[q], acc[R], 0, 0, 0);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cbh[q], acc[R], 0, 0, 0);
                     }
                 }
             } else
-            for (int ks0 = 0; ks0 < KS; ks0 += KSC) {
+            for (int ks0 = kc0; ks0 < kc0 + kcn; ks0 += KSC) {
                 float zv[KSC][8];
 #pragma unroll
                 for (int q = 0; q < KSC; ++q)
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
 #pragma unroll
                 for (int q = 0; q < KSC; ++q) {
                     const int ks = ks0 + q;
-                    if (ks >= KS) break;
+                    if (ks >= kc0 + kcn) break;
                     bf16x8 bh, bl;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -163,14 +168,17 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
                     }
 #pragma unroll
                     for (int R = 0; R < RT; ++R) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 0) * 64 + lane]);
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 1) * 64 + lane]);
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KCH + ks - kc0) * 2 + 0) * 64 + lane]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KCH + ks - kc0) * 2 + 1) * 64 + lane]);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
                         acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
                     }
                 }
             }
+        }
+        __syncthreads();                                    // previous group's gather has read col (and the chunk loop is done)
+        {
             // accumulator register v of tile R is tap 32R + 8(v>>2) + 4h + (v&3) of pixel column c32
 #pragma unroll
             for (int R = 0; R < RT; ++R)
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void k_synth_assemble(cdl_geom g, const float 
 }
 
 struct Plan {
-    int tilesX, tilesY, RT, KS;
+    int tilesX, tilesY, RT, KS, KCH;
     size_t tiles, frag_uint4, patch_floats, lds;
 };
 
@@ -260,7 +268,12 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->frag_uint4 = (size_t)g->C * g->Pd * p->RT * p->KS * 2 * 64;
     const int PY = (TCY - 1) * g->sh + g->Ph, PX = (TCX - 1) * g->sw + g->Pw;
     p->patch_floats = p->tiles * g->C * g->Pd * PY * PX;
-    p->lds = (size_t)p->RT * 32 * TCX * TCY * 4 + (size_t)p->RT * p->KS * 2 * 64 * 16;
+    p->KCH = p->KS;                                        // weight fragments resident per group, or KSC k-steps at a time
+    p->lds = (size_t)p->RT * 32 * TCX * TCY * 4 + (size_t)p->RT * p->KCH * 2 * 64 * 16;
+    if (p->lds > 150 * 1024) {
+        p->KCH = KSC;
+        p->lds = (size_t)p->RT * 32 * TCX * TCY * 4 + (size_t)p->RT * p->KCH * 2 * 64 * 16;
+    }
     if (p->lds > 150 * 1024) return false;
     if (p->tiles >= ((size_t)1 << 31) || g->H > 65535 || (size_t)g->N * g->C * g->D > 65535) return false;
     if (p->patch_floats > ((size_t)1 << 28)) return false;                     // 1 GiB of patches: not worth it
@@ -287,9 +300,9 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
         attr_done = true;
     }
     if (p.KS <= 4 && g->C * g->Pd > 1)       // several groups share the code values: keep their fragments in registers
-        k_synth_m<PH, PW, SW, 4><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
+        k_synth_m<PH, PW, SW, 4><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH);
     else
-        k_synth_m<PH, PW, SW, 0><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS);
+        k_synth_m<PH, PW, SW, 0><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH);
     CDL_LAUNCH_CHECK();
     dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
     k_synth_assemble<PH, PW, SW><<<grid, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);

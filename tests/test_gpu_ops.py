@@ -30,6 +30,9 @@ SHAPES = [
     (48, 1, 6, (132, 72), (7, 7), 2),
     (3, 1, 5, (9, 40, 72), (5, 5, 5), 1),
     (70, 2, 4, (34, 66), (9, 9), 1),
+    # the argscsr.json filter bank: 9 x 9, stride 2, 169 code channels -- weight fragments stream through LDS in
+    # chunks of k-steps in the matrix-core synthesis, channel groups in the analysis
+    (12, 1, 169, (68, 132), (9, 9), 2),
 ]
 
 
