@@ -54,6 +54,8 @@ SIGNATURES = {
     "cdl_ista_forward": [_G, _I] + [_P] * 14 + [ctypes.c_size_t, _P],
     "cdl_ista_backward": [_G, _I] + [_P] * 26 + [ctypes.c_size_t, _P],
     "cdl_nle_mad": [_P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _P],
+    "cdl_residual_forward": [_G, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
+    "cdl_residual_backward": [_G] + [_P] * 11 + [ctypes.c_size_t, _P],
     "cdl_prox_csr": [_G, _P, _P, _P, _P, _P, _P, _P, _P],
     "cdl_prox_csr_bwd": [_G] + [_P] * 15 + [ctypes.c_size_t, _P],
     "cdl_project_filters": [_P, _I, _I, _P],
@@ -77,7 +79,7 @@ SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G]
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
                 "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G], "cdl_analysis_workspace_floats": [_G],
-                "cdl_nle_mad_scratch_floats": [_I, _I, _I, _I]}
+                "cdl_nle_mad_scratch_floats": [_I, _I, _I, _I], "cdl_residual_scratch_floats": [_G]}
 
 _lib = None
 

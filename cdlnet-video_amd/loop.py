@@ -316,6 +316,100 @@ class TemporalISTA(torch.autograd.Function):
                 dg2.reshape(g2.shape) if dg2 is not None else None, None, *dA, *dB)
 
 
+# ------------------------------------------------------------------------------------------
+# CDLNetVideo(residual=True) (reference model/net.py:199-212): a ResidualBlock
+# rewrites the code after every iteration, so the sweep is a chain of per-iteration autograd nodes -- one ISTA
+# iteration (the launches of _forward/_backward_generic_stepwise for one k), one block, ..., the synthesis.
+class _ISTAIteration(torch.autograd.Function):
+    """(z_k | None, t_k (2,M..), A_k, B_k) -> z_{k+1} = ST(z_k - A_k(mask B_k z_k - yp), tau_k)."""
+
+    @staticmethod
+    def forward(ctx, zin, t_k, wA, wB, g, yp, mask_p, c):
+        tau = ops.thresholds(t_k.reshape((1,) + tuple(t_k.shape)), c, g.N)[0]
+        if zin is None:
+            r = yp
+            z = ops.analysis(g, yp, wA, 1.0, None, None, tau)
+        else:
+            r = ops.synthesis(g, zin, wB, 1.0, None, mask_p, yp)
+            z = ops.analysis(g, r, wA, -1.0, zin, None, tau)
+        ctx.g, ctx.first, ctx.t_shape = g, zin is None, tuple(t_k.shape)
+        ctx.mask_p, ctx.c = mask_p, c
+        ctx.save_for_backward(zin if zin is not None else yp.new_empty(0), r, z, wA, wB)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        g = ctx.g
+        zin, r, z, wA, wB = ctx.saved_tensors
+        gk = gz.contiguous()
+        dt_k = torch.zeros((2, g.M), device=gk.device, dtype=torch.float32)
+        ops.tau_grad(g, gk, z, ctx.c, dt_k)
+        dt_k = dt_k.reshape(ctx.t_shape)
+        if ctx.first:
+            dA = ops.wgrad(g, gk, r, 1.0, gate=z)
+            return None, dt_k, dA, None, None, None, None, None
+        q = ops.synthesis(g, gk, wA, -1.0, z, ctx.mask_p, None)
+        dA = ops.wgrad(g, gk, r, -1.0, gate=z)
+        dB = ops.wgrad(g, zin, q, 1.0)
+        gzin = ops.analysis(g, q, wB, 1.0, gk, z, None)
+        return gzin, dt_k, dA, dB, None, None, None, None
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """(x, w1, w2) -> relu(conv2(relu(conv1 x)) + x)  (net.py:113-120)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        g = ops.residual_geometry(x, w1)
+        h, out = ops.residual_forward(g, x.contiguous(), w1, w2)
+        ctx.g = g
+        ctx.save_for_backward(x, h, out, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, h, out, w1, w2 = ctx.saved_tensors
+        dx, dw1, dw2 = ops.residual_backward(ctx.g, x, h, out, w1, w2, g_out.contiguous())
+        return dx, dw1, dw2
+
+
+class _Dictionary(torch.autograd.Function):
+    """(z_K, B_0) -> xhat = post_process(D z_K)."""
+
+    @staticmethod
+    def forward(ctx, z, wB, g, mean, pads):
+        xp = ops.synthesis(g, z, wB, 1.0)
+        ctx.g, ctx.pads = g, pads
+        ctx.save_for_backward(z, wB)
+        return ops.postprocess(xp, mean, pads)
+
+    @staticmethod
+    def backward(ctx, g_xhat):
+        z, wB = ctx.saved_tensors
+        g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads)
+        dB = ops.wgrad(ctx.g, z, g_xp, 1.0)
+        gz = ops.analysis(ctx.g, g_xp, wB, 1.0, None, None, None)
+        return gz, dB, None, None, None
+
+
+def run_residual(y, mask, c, t, A, B, s, blocks, all_codes=False):
+    """CDLNetVideo.forward with residual=True: blocks[k] = (w1, w2) applied after iteration k.
+    Returns (xhat, z) or, with all_codes, (xhat, z, ST outputs of every iteration) as forward_generator
+    yields them (net.py:218-224: the code BEFORE its block)."""
+    K = len(A)
+    yp, mean, pads, mask_p = ops.preprocess(y, s, mask)
+    N, C = yp.shape[:2]
+    P = tuple(A[0].shape[2:])
+    g = ops.Geometry.make(N, C, A[0].shape[0], yp.shape[2:], P, tuple(p // 2 for p in P), [s] * (yp.dim() - 2))
+    z, shrunk = None, []
+    for k in range(K):
+        z = _ISTAIteration.apply(z, t[k], A[k], B[k], g, yp, mask_p, c)
+        shrunk.append(z)
+        z = ResidualBlockFn.apply(z, *blocks[k])
+    xhat = _Dictionary.apply(z, B[0], g, mean, pads)
+    return (xhat, z, *shrunk) if all_codes else (xhat, z)
+
+
 def run_csr(y, mask, c, z_prev, z_after, t, g1, g2, A, B, s):
     """Front end of the neighbour branches; the no-neighbour branch is `run`."""
     cfg = {"K": len(A), "s": int(s)}

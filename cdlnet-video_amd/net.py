@@ -295,15 +295,41 @@ class CDLNet_CSRf2(_CSRBase):
 
 
 # ------------------------------------------------------------------------------------------ 3-D
+class _DenseConv3d(nn.Conv3d):
+    """Parameter holder of a ResidualBlock convolution; stand-alone forward = the HIP analysis operator."""
+
+    def forward(self, x):
+        g = ops.residual_geometry(x, self.weight)
+        return ops.analysis(g, x, self.weight.detach())
+
+
+class ResidualBlock(nn.Module):
+    """net.py:105-120: relu(conv2(relu(conv1 x)) + x) with two bias-free 3x3x3 convolutions, on the HIP
+    operators (forward and backward: loop.ResidualBlockFn).  Same constructor and state_dict keys."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3, 3), stride=1, padding=1):
+        super().__init__()
+        ks = (kernel_size,) * 3 if isinstance(kernel_size, int) else tuple(kernel_size)
+        pd = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+        if in_channels != out_channels or stride != 1 or any(k % 2 == 0 for k in ks) or pd != tuple(k // 2 for k in ks):
+            raise ValueError("ResidualBlock: the skip connection needs in == out channels, stride 1 and "
+                             "'same' padding (the only form the reference builds, net.py:150)")
+        self.conv1 = _DenseConv3d(in_channels, out_channels, ks, stride=1, padding=pd, bias=False)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _DenseConv3d(out_channels, out_channels, ks, stride=1, padding=pd, bias=False)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("ResidualBlock.forward: this package has no CPU compute path")
+        return loop.ResidualBlockFn.apply(x.to(torch.float32), self.conv1.weight, self.conv2.weight)
+
+
 class CDLNetVideo(_ISTANet):
     """3-D (video / volume) twin; `P` is (kD, kH, kW) or an int (cube)."""
 
     def __init__(self, K=3, M=64, P=(7, 7, 5), s=1, C=1, t0=0, adaptive=False, depth=3, init=True,
                  residual=False):
         super().__init__()
-        if residual:
-            raise NotImplementedError("residual=True (ResidualBlock, net.py:105-120) is outside the "
-                                      "hot path this package replaces; no shipped config enables it")
         if isinstance(P, int):
             P = (P, P, P)
         P = tuple(int(p) for p in P)
@@ -316,7 +342,9 @@ class CDLNetVideo(_ISTANet):
                                              bias=False) for _ in range(K)])
         self.D = self.B[0]
         self.t = nn.Parameter(t0 * torch.ones(K, 2, M, 1, 1, 1))
-        self.residual = False
+        self.residual = bool(residual)
+        if self.residual:                       # created here, as the reference does: same RNG draws
+            self.residual_blocks = nn.ModuleList([ResidualBlock(M, M) for _ in range(K)])
         W = torch.randn(M, C, *P)
         for k in range(K):
             self.A[k].weight.data = W.clone()
@@ -334,6 +362,26 @@ class CDLNetVideo(_ISTANet):
                 self.A[k].weight.data /= np.sqrt(L)
                 self.B[k].weight.data /= np.sqrt(L)
         self.K, self.M, self.P, self.s, self.t0, self.adaptive = K, M, P, s, t0, adaptive
+
+    def _run(self, y, sigma, mask, all_codes):
+        if not self.residual:
+            return super()._run(y, sigma, mask, all_codes)
+        if not y.is_cuda:
+            raise RuntimeError(f"CDLNetVideo.forward: input is on {y.device}; this package has no CPU compute path")
+        y = y.to(torch.float32)
+        A, B = self._filters()
+        c = _noise_scale(sigma, self.adaptive, y.shape[0], y.device)
+        blocks = [(b.conv1.weight, b.conv2.weight) for b in self.residual_blocks]
+        return loop.run_residual(y, _mask_tensor(mask, y), c, self.t, A, B, self.s, blocks, all_codes)
+
+    def forward_generator(self, y, sigma=None, mask=1):
+        """net.py:214-227; with residual blocks the yielded codes are the ST outputs (before the block)."""
+        if not self.residual:
+            yield from super().forward_generator(y, sigma, mask)
+            return
+        outs = self._run(y, sigma, mask, True)
+        yield from outs[2:]
+        yield outs[0]
 
     @torch.no_grad()
     def project(self):

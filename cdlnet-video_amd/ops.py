@@ -322,6 +322,44 @@ def prox_csr_bwd(g: Geometry, gz, u, z_prev, lam, gam1, c, dlam, dgam1, z_after=
     return out
 
 
+def residual_geometry(x, w):
+    """Geometry of a ResidualBlock conv (net.py:105-120): C == M channels, unit stride, padding P//2."""
+    M = int(w.shape[0])
+    if tuple(w.shape[:2]) != (M, M) or x.shape[1] != M:
+        raise ValueError(f"ResidualBlock expects (M,M,...) filters and M-channel input, got {tuple(w.shape)} / {tuple(x.shape)}")
+    P = tuple(w.shape[2:])
+    return Geometry.make(x.shape[0], M, M, x.shape[2:], P, tuple(p // 2 for p in P), 1)
+
+
+def residual_forward(g: Geometry, x, w1, w2):
+    """(h, out) = (relu(conv1 x), relu(conv2 h + x)); h is what the reverse pass keeps."""
+    x, w1, w2 = _dev(x, "x"), _dev(w1, "w1"), _dev(w2, "w2")
+    assert tuple(x.shape) == g.code_shape() and tuple(w1.shape) == g.filter_shape() == tuple(w2.shape)
+    h, out = torch.empty_like(x), torch.empty_like(x)
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_residual_scratch_floats(ctypes.byref(gs)))
+    ws = _scratch(x.device, n) if n else None
+    rc = _lib.lib().cdl_residual_forward(ctypes.byref(gs), _ptr(x), _ptr(w1), _ptr(w2), _ptr(h), _ptr(out),
+                                         _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_residual_forward")
+    return h, out
+
+
+def residual_backward(g: Geometry, x, h, out, w1, w2, g_out):
+    """(dx, dw1, dw2) for g_out = dL/dout."""
+    g_out = _dev(g_out, "g_out")
+    dx, dh = torch.empty_like(x), torch.empty_like(x)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_residual_scratch_floats(ctypes.byref(gs)))
+    ws = _scratch(x.device, n) if n else None
+    rc = _lib.lib().cdl_residual_backward(ctypes.byref(gs), _ptr(x), _ptr(h), _ptr(out), _ptr(w1), _ptr(w2),
+                                          _ptr(g_out), _ptr(dx), _ptr(dw1), _ptr(dw2), _ptr(dh), _ptr(ws), n,
+                                          _stream())
+    _lib.check(rc, "cdl_residual_backward")
+    return dx, dw1, dw2
+
+
 def project_filters_(w):
     """In-place unit-ball projection of every (m,c) filter of w (M,C,*P)."""
     if not w.is_cuda:

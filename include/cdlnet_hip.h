@@ -178,6 +178,19 @@ size_t cdl_nle_mad_scratch_floats(int N, int C, int H, int W);
 int cdl_nle_mad(const float *y, float *sigma_hat /*N*/, float *scratch, size_t scratch_floats, int N, int C,
                 int H, int W, void *stream);
 
+/* ---- ResidualBlock of CDLNetVideo(residual=True) -------------------------
+ * model/net.py:105-120, applied to the code after every iteration (net.py:199-207):
+ *     h = relu(conv1(x)),  out = relu(conv2(h) + x),   conv*: Conv3d(M, M, P, stride 1, padding P/2, bias=False)
+ * g: a geometry with C == M (the block's channels), unit strides, (D,H,W) the code extents; w1, w2 (M,M,Pd,Ph,Pw).
+ * forward writes h (kept for the reverse pass) and out; backward takes g_out = dL/dout and writes dx, dw1, dw2,
+ * using dh (code-sized scratch).  x, h, out, dh, dx are (N,M,D,H,W).  scratch: cdl_residual_scratch_floats(g). */
+size_t cdl_residual_scratch_floats(const cdl_geom *g);
+int cdl_residual_forward(const cdl_geom *g, const float *x, const float *w1, const float *w2, float *h, float *out,
+                         float *scratch, size_t scratch_floats, void *stream);
+int cdl_residual_backward(const cdl_geom *g, const float *x, const float *h, const float *out, const float *w1,
+                          const float *w2, const float *g_out, float *dx, float *dw1, float *dw2, float *dh,
+                          float *scratch, size_t scratch_floats, void *stream);
+
 /* ---- whole sweeps of the shape-generic loop in one call ------------------------------------------
  * The same launches as K x (cdl_synthesis_ws, cdl_analysis | cdl_analysis_prox) + the final synthesis,
  * resp. the reverse sweep (cdl_tau_grad | cdl_prox_csr_bwd, cdl_synthesis_ws, 2 x cdl_wgrad, cdl_analysis

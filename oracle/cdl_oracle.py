@@ -175,6 +175,34 @@ def ista(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, ndim=2, gab
     return (xhat, codes) if all_codes else (xhat, codes[-1])
 
 
+# --------------------------------------------------------------------------- residual blocks (3-D)
+def residual_block(x, w1, w2):
+    """model/net.py:113-120: relu(conv2(relu(conv1 x)) + x), bias-free 'same' convolutions, stride 1."""
+    pad = tuple(p // 2 for p in w1.shape[2:])
+    h = torch.relu(F.conv3d(x, w1, padding=pad))
+    return torch.relu(F.conv3d(h, w2, padding=pad) + x)
+
+
+def ista_video_residual(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, all_codes=False):
+    """CDLNetVideo.forward with residual=True (model/net.py:192-212): a ResidualBlock rewrites the code after
+    every iteration.  all_codes: also the ST outputs (what forward_generator yields, net.py:218-224)."""
+    yp, mean, pads, mask_p = preprocess(y, s, mask)
+    c = 0.0 if (sigma is None or not adaptive) else sigma / 255.0
+    pad = _conv_pad(P, 3)
+    A, B = _weights_from_state(sd, K)
+    blk = lambda k, z: residual_block(z, sd[f"residual_blocks.{k}.conv1.weight"], sd[f"residual_blocks.{k}.conv2.weight"])
+    shrunk = [soft_threshold(analysis(yp, A[0], s, pad), _thresholds(sd["t"], 0, c))]
+    z = blk(0, shrunk[0])
+    for k in range(1, K):
+        resid = synthesis(z, B[k], s, pad)
+        if mask_p is not None:
+            resid = mask_p * resid
+        shrunk.append(soft_threshold(z - analysis(resid - yp, A[k], s, pad), _thresholds(sd["t"], k, c)))
+        z = blk(k, shrunk[-1])
+    xhat = postprocess(synthesis(z, B[0], s, pad), mean, pads)
+    return (xhat, z, shrunk) if all_codes else (xhat, z)
+
+
 # --------------------------------------------------------------------------- blind noise level (MAD)
 # PyWavelets' 'bior4.4' filter bank (pywt.Wavelet('bior4.4').filter_bank: dec_lo, dec_hi, rec_lo, rec_hi),
 # restated from the published CDF 9/7 pair because pywt is not installed here ("parity unpinned" against

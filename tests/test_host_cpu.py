@@ -87,8 +87,13 @@ def test_state_dict_surface():
     assert "g" not in sdv and sdv["t"].shape == (2, 2, 4, 1, 1, 1)
     assert sdv["A.0.weight"].shape == (4, 1, 9, 9, 5)
     assert cva.CDLNetVideo(K=1, M=2, P=7, init=False).P == (7, 7, 7)     # args3d.json's int P
-    with pytest.raises(NotImplementedError):
-        cva.CDLNetVideo(K=1, M=2, P=3, init=False, residual=True)
+    res = cva.CDLNetVideo(K=2, M=4, P=3, init=False, residual=True)        # net.py:146-151
+    assert res.state_dict()["residual_blocks.1.conv2.weight"].shape == (4, 4, 3, 3, 3)
+    assert isinstance(res.residual_blocks[0], cva.ResidualBlock) and isinstance(res.residual_blocks[0].relu, torch.nn.ReLU)
+    with pytest.raises(RuntimeError):                                      # no CPU compute path
+        res(torch.zeros(1, 1, 3, 8, 8))
+    with pytest.raises(ValueError):
+        cva.ResidualBlock(4, 8)
     for attr in ("K", "M", "P", "s", "t0", "adaptive"):
         assert hasattr(net, attr) and hasattr(vid, attr)
 
