@@ -111,6 +111,11 @@ int cdl_mfma_synthesis(const cdl_geom *g, const float *z, const float *gate, con
                        const float *mask, const float *sub, float *out, float *ws, size_t ws_floats, void *stream);
 size_t cdl_mfma_synthesis_ws_floats(const cdl_geom *g);
 // matrix-core analysis (cdl_analysis_mfma.hip), same convention
+// cdl_dense_mfma.hip: many-channel unit-stride convolution (C >= 16 on both sides), analysis or synthesis role
+size_t cdl_dense_ws_floats(const cdl_geom *g, int transpose);
+int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float *in_gate, const float *w,
+                   float alpha, const float *add, const float *add_gate, const float *mask, const float *sub,
+                   const float *tau, int relu, float *out, float *ws, size_t ws_floats, void *stream);
 int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                       const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
                       size_t ws_floats, void *stream);

@@ -1,0 +1,273 @@
+// Dense (many-channel to many-channel) unit-stride convolution on the matrix cores: the tier of cdl_analysis /
+// cdl_synthesis for geometries with C >= 16 "image" channels -- the Conv3d(M, M, 3x3x3) of the reference's
+// ResidualBlock (model/net.py:105-120) and its data gradient.  With many input channels the natural GEMM k index
+// is the input channel at a fixed filter tap (the sparse-dictionary kernels of cdl_analysis_mfma.hip put the taps
+// on k and gather an im2col operand; here no gather is needed):
+//     out[o, p] = sum_{tap} sum_{i} W_tap[o, i] * x[i, p + tap]
+// is, per tap, a (32R+l32 = o) x (k = i) by (k = i) x (l32 = pixel) MFMA product whose B operand is 8 consecutive
+// channels of one pixel: one 16-byte LDS read from a [pixel][channel] bf16 plane.
+//
+// Workgroup (512 threads, 8 waves): a 32 x 16 tile of output pixels at one depth, MT <= 2 tiles of 32 output
+// channels (more: blockIdx.y); wave w owns rows 2w, 2w+1.  The k loop runs over stages = (16-channel chunk, kd):
+// each stage parks the (16+Ph-1) x (32+Pw-1) x 16-channel input window (fp32 -> bf16 hi + lo) and that stage's
+// Ph*Pw weight fragments in LDS (75 KB for 3x3: two workgroups per CU overlap each other's staging), then issues
+// Ph*Pw taps x 2 rows x MT x 3 MFMAs (split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// Epilogue straight from the accumulators (lanes l32 = 32 consecutive x: 128-byte segments):
+//     v = alpha * acc;  v *= mask;  v += add [where add_gate != 0];  v -= sub;  v = ST(v, tau);  v = max(v, 0)
+// which covers the analysis role (add = zin, tau), the synthesis role (transposed + flipped weights, input gate,
+// mask, sub) and the ResidualBlock's fused relu.
+#include "cdl_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+namespace {
+
+constexpr int DTX = 32, DTY = 16, DNT = 512, DKC = 16;
+
+struct DenseArgs {
+    const float *x, *in_gate;
+    const uint4 *frags;
+    float alpha;
+    const float *add, *add_gate, *mask, *sub, *tau;
+    int relu;
+    float *out;
+    int N, I, O, D, H, W, Pd, Ph, Pw, tilesX, tilesY, NCC, MTT;
+};
+
+// frags[(((cc*Pd + kd)*taps + tap)*MTT + R)*2 + {hi,lo}][64]: lane (l32, h) holds output channel o = 32R + l32,
+// input channels i = 16cc + 8h + 0..7 of W_tap.  transpose: the filters are (I, O, P) and flipped (conv-transpose).
+__global__ void k_dense_prep(const float *__restrict__ w, uint4 *__restrict__ frags, int O, int I, int Pd, int Ph,
+                             int Pw, int MTT, int NCC, int transpose)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int taps = Ph * Pw;
+    if (t >= NCC * Pd * taps * MTT * 64) return;
+    const int lane = t & 63;
+    int r = t >> 6;
+    const int R = r % MTT; r /= MTT;
+    const int tap = r % taps; r /= taps;
+    const int kd = r % Pd, cc = r / Pd;
+    const int o = 32 * R + (lane & 31), h = lane >> 5, ki = tap / Pw, kj = tap % Pw;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = DKC * cc + 8 * h + e;
+        float v = 0.0f;
+        if (o < O && i < I)
+            v = transpose ? w[((((size_t)i * O + o) * Pd + (Pd - 1 - kd)) * Ph + (Ph - 1 - ki)) * Pw + (Pw - 1 - kj)]
+                          : w[((((size_t)o * I + i) * Pd + kd) * Ph + ki) * Pw + kj];
+        const __bf16 hh = (__bf16)v;
+        hi[e] = hh;
+        lo[e] = (__bf16)(v - (float)hh);
+    }
+    const size_t base = (size_t)(t >> 6) * 2 * 64;
+    frags[base + lane] = __builtin_bit_cast(uint4, hi);
+    frags[base + 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+template <int MT>
+__global__ __launch_bounds__(DNT, 2) void k_dense(DenseArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int XH = DTY + a.Ph - 1, XW = DTX + a.Pw - 1, taps = a.Ph * a.Pw;
+    const int npix = XH * XW;
+    uint4 *xh = reinterpret_cast<uint4 *>(smem);           // [npix][2 halves] 8 bf16 each (hi parts)
+    uint4 *xl = xh + (size_t)npix * 2;                     // lo parts
+    uint4 *wl = xl + (size_t)npix * 2;                     // [taps][MT][2][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    int b = blockIdx.x;
+    const int tx = b % a.tilesX; b /= a.tilesX;
+    const int ty = b % a.tilesY; b /= a.tilesY;
+    const int zd = b % a.D, n = b / a.D;
+    const int r0 = blockIdx.y * MT;
+    const int pd = a.Pd / 2, ph = a.Ph / 2, pw = a.Pw / 2;
+    const size_t plane = (size_t)a.H * a.W, slab = (size_t)a.D * plane;
+
+    f32x16 acc[2][MT];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int R = 0; R < MT; ++R)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[rr][R][v] = 0.0f;
+
+    const int stages = a.NCC * a.Pd;
+#pragma unroll 1
+    for (int st = 0; st < stages; ++st) {
+        const int cc = st / a.Pd, kd = st % a.Pd;
+        const int d = zd - pd + kd;
+        if (d < 0 || d >= a.D) continue;                   // uniform: a plane of zero padding
+        __syncthreads();                                   // the previous stage's readers are done
+        // input window: (pixel, half) items, consecutive threads on consecutive x
+        for (int it = threadIdx.x; it < npix * 2; it += DNT) {
+            const int half = it / npix, pix = it - half * npix;
+            const int row = pix / XW, col = pix - row * XW;
+            const int yy = ty * DTY - ph + row, xx = tx * DTX - pw + col;
+            const int c0 = DKC * cc + 8 * half;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)yy * a.W + xx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < a.I) v[e] = a.x[base + e * slab];
+                if (a.in_gate) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + e < a.I && a.in_gate[base + e * slab] == 0.0f) v[e] = 0.0f;
+                }
+            }
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hh = (__bf16)v[e];
+                hi[e] = hh;
+                lo[e] = (__bf16)(v[e] - (float)hh);
+            }
+            xh[pix * 2 + half] = __builtin_bit_cast(uint4, hi);
+            xl[pix * 2 + half] = __builtin_bit_cast(uint4, lo);
+        }
+        // this stage's weight fragments for channel tiles r0 .. r0+MT-1
+        for (int i = threadIdx.x; i < taps * MT * 128; i += DNT) {
+            const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
+            wl[i] = a.frags[((size_t)(st * taps + tap) * a.MTT + r0) * 128 + rem];
+        }
+        __syncthreads();
+        int ki = 0, kj = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < taps; ++tap) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int pix = (2 * wv + rr + ki) * XW + l32 + kj;
+                bh[rr] = __builtin_bit_cast(bf16x8, xh[pix * 2 + h]);
+                bl[rr] = __builtin_bit_cast(bf16x8, xl[pix * 2 + h]);
+            }
+#pragma unroll
+            for (int R = 0; R < MT; ++R) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + lane]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + 64 + lane]);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[rr], acc[rr][R], 0, 0, 0);
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[rr], acc[rr][R], 0, 0, 0);
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[rr], acc[rr][R], 0, 0, 0);
+                }
+            }
+            if (++kj == a.Pw) { kj = 0; ++ki; }
+        }
+    }
+
+    // epilogue: register v of tile R is output channel 32(r0+R) + 8(v>>2) + 4h + (v&3) of pixel column l32
+    const int x = tx * DTX + l32;
+    const size_t nbase = (size_t)n * a.O * slab + (size_t)zd * plane;   // offsets inside the sample are 32-bit
+    const float *add_n = a.add ? a.add + nbase : nullptr;
+    const float *ag_n = (a.add && a.add_gate) ? a.add_gate + nbase : nullptr;
+    const float *mask_n = a.mask ? a.mask + nbase : nullptr;
+    const float *sub_n = a.sub ? a.sub + nbase : nullptr;
+    float *out_n = a.out + nbase;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = ty * DTY + 2 * wv + rr;
+        if (y >= a.H || x >= a.W) continue;
+        const int pix = y * a.W + x;
+#pragma unroll
+        for (int R = 0; R < MT; ++R) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = 32 * (r0 + R) + 8 * (v >> 2) + 4 * h + (v & 3);
+                if (m >= a.O) continue;
+                const int idx = m * (int)slab + pix;
+                float val = a.alpha * acc[rr][R][v];
+                if (mask_n) val *= mask_n[idx];
+                if (add_n) {
+                    const float av = add_n[idx];
+                    if (!ag_n || ag_n[idx] != 0.0f) val += av;
+                }
+                if (sub_n) val -= sub_n[idx];
+                if (a.tau) val = cdl_shrink(val, a.tau[n * a.O + m]);
+                if (a.relu) val = fmaxf(val, 0.0f);
+                out_n[idx] = val;
+            }
+        }
+    }
+}
+
+struct DensePlan {
+    int tilesX, tilesY, NCC, MTT, MT, ngy;
+    size_t frag_uint4, lds, tiles;
+};
+
+// in: channels on the input side, out: on the output side (analysis role: C -> M; synthesis role: M -> C)
+bool dense_plan(const cdl_geom *g, int in, int out, DensePlan *p)
+{
+    if (g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
+    if (in < 16 || out < 16) return false;                 // few channels: the sparse-dictionary kernels
+    if (g->Ph > 5 || g->Pw > 5 || !(g->Pd & 1) || !(g->Ph & 1) || !(g->Pw & 1)) return false;
+    if (g->pd != g->Pd / 2 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
+    const size_t slab = (size_t)g->D * g->H * g->W;
+    if ((size_t)out * slab >= ((size_t)1 << 31)) return false;            // 32-bit offsets inside one sample
+    p->NCC = (in + DKC - 1) / DKC;
+    p->MTT = (out + 31) / 32;
+    p->MT = p->MTT >= 2 ? 2 : 1;
+    p->ngy = (p->MTT + p->MT - 1) / p->MT;
+    p->MTT = p->ngy * p->MT;                                // padded to whole groups
+    p->tilesX = (g->W + DTX - 1) / DTX;
+    p->tilesY = (g->H + DTY - 1) / DTY;
+    p->tiles = (size_t)g->N * g->D * p->tilesX * p->tilesY;
+    if (p->tiles >= ((size_t)1 << 31) || p->ngy > 65535) return false;
+    const int taps = g->Ph * g->Pw;
+    p->frag_uint4 = (size_t)p->NCC * g->Pd * taps * p->MTT * 128;
+    const size_t npix = (size_t)(DTY + g->Ph - 1) * (DTX + g->Pw - 1);
+    p->lds = npix * 2 * 2 * 16 + (size_t)taps * p->MT * 128 * 16;
+    return p->lds <= 160 * 1024;
+}
+
+template <int MT>
+int launch_dense(const DensePlan &p, const DenseArgs &a, hipStream_t st)
+{
+    static size_t attr = 0;
+    if (p.lds > 64 * 1024 && p.lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_dense<MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr = 160 * 1024;
+    }
+    k_dense<MT><<<dim3((unsigned)p.tiles, (unsigned)p.ngy), DNT, p.lds, st>>>(a);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+size_t cdl_dense_ws_floats(const cdl_geom *g, int transpose)
+{
+    DensePlan p;
+    const int in = transpose ? g->M : g->C, out = transpose ? g->C : g->M;
+    return dense_plan(g, in, out, &p) ? p.frag_uint4 * 4 : 0;
+}
+
+// transpose = 0: x (N,C,..) -> out (N,M,..) with filters (M,C,P) (the analysis role)
+// transpose = 1: x (N,M,..) -> out (N,C,..), the conv-transpose with the same filters (the synthesis role)
+// CDL_EUNSUPPORTED: the caller falls back to the other tiers.
+int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float *in_gate, const float *w,
+                   float alpha, const float *add, const float *add_gate, const float *mask, const float *sub,
+                   const float *tau, int relu, float *out, float *ws, size_t ws_floats, void *stream)
+{
+    DensePlan p;
+    const int in = transpose ? g->M : g->C, outc = transpose ? g->C : g->M;
+    if (!dense_plan(g, in, outc, &p)) return CDL_EUNSUPPORTED;
+    if (!ws || ws_floats < p.frag_uint4 * 4 || (reinterpret_cast<size_t>(ws) & 15)) return CDL_EUNSUPPORTED;
+    uint4 *frags = reinterpret_cast<uint4 *>(ws);
+    const int nprep = p.NCC * g->Pd * g->Ph * g->Pw * p.MTT * 64;
+    k_dense_prep<<<(nprep + 255) / 256, 256, 0, S(stream)>>>(w, frags, outc, in, g->Pd, g->Ph, g->Pw, p.MTT, p.NCC,
+                                                              transpose);
+    CDL_LAUNCH_CHECK();
+    const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, relu, out,
+                      g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT};
+    return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));
+}

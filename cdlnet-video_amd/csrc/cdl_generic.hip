@@ -577,10 +577,19 @@ static bool mfma_analysis_enabled(const cdl_geom *g)
     return true;
 }
 
+// the dense many-channel tier (cdl_dense_mfma.hip; C >= 16 on both sides, unit stride); CDL_MFMA_DENSE=0 disables
+static bool mfma_dense_enabled()
+{
+    const char *e = getenv("CDL_MFMA_DENSE");
+    return !(e && e[0] == '0');
+}
+
 size_t cdl_analysis_workspace_floats(const cdl_geom *g)
 {
-    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED") || !mfma_analysis_enabled(g)) return 0;
-    return cdl_mfma_analysis_ws_floats(g);
+    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
+    const size_t a = mfma_analysis_enabled(g) ? cdl_mfma_analysis_ws_floats(g) : 0;
+    const size_t b = mfma_dense_enabled() ? cdl_dense_ws_floats(g, 0) : 0;
+    return a > b ? a : b;
 }
 
 int cdl_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
@@ -622,6 +631,11 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
     if (out == zin) return CDL_EINVAL;
     if (gate && !zin) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
+        if (!px.zp && mfma_dense_enabled()) {
+            const int rcd = cdl_dense_conv(g, 0, x, nullptr, w, alpha, zin, gate, nullptr, nullptr, tau, 0, out, ws,
+                                           ws_floats, stream);
+            if (rcd != CDL_EUNSUPPORTED) return rcd;
+        }
         if (mfma_analysis_enabled(g)) {
             const int rcm = cdl_mfma_analysis(g, x, w, alpha, zin, gate, tau, out, px, ws, ws_floats, stream);
             if (rcm != CDL_EUNSUPPORTED) return rcm;
@@ -657,7 +671,9 @@ size_t cdl_synthesis_workspace_floats(const cdl_geom *g)
 {
     if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
     const size_t a = cdl_tiled_synthesis_ws_floats(g);
-    const size_t b = mfma_synthesis_enabled() ? cdl_mfma_synthesis_ws_floats(g) : 0;
+    size_t b = mfma_synthesis_enabled() ? cdl_mfma_synthesis_ws_floats(g) : 0;
+    const size_t d = mfma_dense_enabled() ? cdl_dense_ws_floats(g, 1) : 0;
+    if (d > b) b = d;
     return a > b ? a : b;
 }
 
@@ -673,6 +689,11 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
 {
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
+        if (mfma_dense_enabled()) {
+            const int rcd = cdl_dense_conv(g, 1, z, gate, w, alpha, nullptr, nullptr, mask, sub, nullptr, 0, out,
+                                           workspace, workspace_floats, stream);
+            if (rcd != CDL_EUNSUPPORTED) return rcd;
+        }
         if (mfma_synthesis_enabled()) {
             const int rcm = cdl_mfma_synthesis(g, z, gate, w, alpha, mask, sub, out, workspace, workspace_floats, stream);
             if (rcm != CDL_EUNSUPPORTED) return rcm;

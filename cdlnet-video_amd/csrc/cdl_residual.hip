@@ -77,6 +77,16 @@ int cdl_residual_forward(const cdl_geom *g, const float *x, const float *w1, con
     if (!block_geom_ok(g) || !x || !w1 || !w2 || !h || !out || h == x || out == x || out == h) return CDL_EINVAL;
     if (scratch_floats < cdl_residual_scratch_floats(g) || (scratch_floats && !scratch)) return CDL_EINVAL;
     const size_t n = (size_t)g->N * g->M * g->D * g->H * g->W;
+    // dense matrix-core tier: the relu is the convolution's epilogue (2 launches + 2 fragment preps per block)
+    const char *e = getenv("CDL_MFMA_DENSE");
+    if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED")) {
+        const int rc = cdl_dense_conv(g, 0, x, nullptr, w1, 1.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 1, h,
+                                      scratch, scratch_floats, stream);
+        if (rc == 0)
+            return cdl_dense_conv(g, 0, h, nullptr, w2, 1.0f, x, nullptr, nullptr, nullptr, nullptr, 1, out, scratch,
+                                  scratch_floats, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
     CDL_TRY(cdl_analysis_ws(g, x, w1, 1.0f, nullptr, nullptr, nullptr, h, scratch, scratch_floats, stream));
     CDL_TRY(relu_inplace(h, n, S(stream)));
     CDL_TRY(cdl_analysis_ws(g, h, w2, 1.0f, x, nullptr, nullptr, out, scratch, scratch_floats, stream));
@@ -94,6 +104,14 @@ int cdl_residual_backward(const cdl_geom *g, const float *x, const float *h, con
     CDL_TRY(cdl_synthesis_ws(g, g_out, out, w2, 1.0f, nullptr, nullptr, dh, scratch, scratch_floats, stream));
     CDL_TRY(cdl_wgrad(g, g_out, out, h, 1.0f, dw2, scratch, scratch_floats, stream));
     CDL_TRY(cdl_wgrad(g, dh, h, x, 1.0f, dw1, scratch, scratch_floats, stream));
+    {   // dense tier: the skip connection's g2 is added in the data-gradient launch's epilogue
+        const char *e = getenv("CDL_MFMA_DENSE");
+        if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED")) {
+            const int rc = cdl_dense_conv(g, 1, dh, h, w1, 1.0f, g_out, out, nullptr, nullptr, nullptr, 0, dx, scratch,
+                                          scratch_floats, stream);
+            if (rc != CDL_EUNSUPPORTED) return rc;
+        }
+    }
     CDL_TRY(cdl_synthesis_ws(g, dh, h, w1, 1.0f, nullptr, nullptr, dx, scratch, scratch_floats, stream));
     k_add_gated<<<(unsigned)((n + 255) / 256), 256, 0, S(stream)>>>(dx, g_out, out, n);
     CDL_LAUNCH_CHECK();

@@ -33,6 +33,11 @@ SHAPES = [
     # the argscsr.json filter bank: 9 x 9, stride 2, 169 code channels -- weight fragments stream through LDS in
     # chunks of k-steps in the matrix-core synthesis, channel groups in the analysis
     (12, 1, 169, (68, 132), (9, 9), 2),
+    # many channels on both sides, unit stride: the dense matrix-core tier (cdl_dense_mfma.hip; the ResidualBlock's
+    # Conv3d(M, M) and its data gradient), ragged channel chunks (24 = 16 + 8), M over two workgroup groups, 2-D
+    (2, 16, 32, (3, 17, 33), (3, 3, 3), 1),
+    (1, 24, 40, (20, 45), (3, 3), 1),
+    (1, 20, 70, (2, 9, 34), (1, 5, 5), 1),
 ]
 
 
@@ -52,6 +57,7 @@ def test_analysis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
     """Both analysis paths: the matrix-core kernel (default where it exists: >= 96 workgroups of 4 tiles; smaller
     launches fall through) and the fp32 VALU kernels (CDL_MFMA_ANALYSIS=0)."""
     monkeypatch.setenv("CDL_MFMA_ANALYSIS", "1" if path == "mfma" else "0")
+    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s)
     pad = tuple(p // 2 for p in P)
@@ -79,6 +85,7 @@ def test_synthesis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
     """Both synthesis paths: the matrix-core kernels (split-bf16 x3; default wherever they exist, the other
     shapes fall through to the VALU kernels) and the fp32 VALU kernels (CDL_MFMA_SYNTHESIS=0, read per call)."""
     monkeypatch.setenv("CDL_MFMA_SYNTHESIS", "1" if path == "mfma" else "0")
+    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=1)
     pad = tuple(p // 2 for p in P)

@@ -44,8 +44,13 @@ def test_video_residual_matches_reference_fixture(name, adaptive, code_loss):
     assert abs(float(loss.detach()) - g["loss"]) < 1e-5 * max(1.0, abs(g["loss"]))
     loss.backward()
     params = dict(net.named_parameters())
+    failures = []
     for key, ref in g["grad"].items():
-        check(f"{name} grad {key}", params[key].grad, ref, 2e-4)
+        try:
+            check(f"{name} grad {key}", params[key].grad, ref, 1e-4)
+        except AssertionError as e:
+            failures.append(str(e))
+    assert not failures, failures
     # forward_generator: the ST outputs, then xhat
     with torch.no_grad():
         outs = list(net.forward_generator(g["y"].cuda(), sigma))
@@ -61,19 +66,38 @@ def test_video_residual_matches_reference_fixture(name, adaptive, code_loss):
 @pytest.mark.parametrize("N,M,shape", [(1, 64, (6, 40, 72)), (2, 32, (3, 17, 33)), (1, 16, (4, 8, 8)),
                                        (1, 48, (5, 24, 36))])
 def test_block_vs_oracle_dense_shapes(N, M, shape):
-    """Channel counts and extents on both sides of the matrix-core tier's eligibility (M % 16, tile edges)."""
+    """Channel counts and extents on both sides of the matrix-core tier's eligibility (M % 16, tile edges).
+    Forward: 1e-5 on h and out, and the ReLU supports agree except where a pre-activation is within the
+    split-bf16 error of 0 (a handful of ~1e5 elements).  Backward: the block is linear given its two gates, so the
+    gradients are checked against autograd on the oracle's convolutions with the PRODUCT's gates -- a single
+    flipped gate would otherwise move one element of grad_x by its full magnitude (max-norm 1e-1)."""
+    import torch.nn.functional as F
+    o = cva.ops
     gen = torch.Generator().manual_seed(100 + M)
     x = torch.randn((N, M) + shape, generator=gen) * 0.5
     w1 = torch.randn((M, M, 3, 3, 3), generator=gen) / (27 * M) ** 0.5
     w2 = torch.randn((M, M, 3, 3, 3), generator=gen) / (27 * M) ** 0.5
     wgt = torch.randn((N, M) + shape, generator=gen)
+    geom = o.residual_geometry(x, w1)
+    xd, w1d, w2d = x.cuda(), w1.cuda(), w2.cuda()
+    h, out = o.residual_forward(geom, xd, w1d, w2d)
+    ref_h = torch.relu(F.conv3d(x, w1, padding=1))
+    ref = orc.residual_block(x, w1, w2)
+    tag = f"block M={M} {shape}"
+    check(tag + " h", h, ref_h, 1e-5)
+    check(tag + " out", out, ref, 1e-5)
+    G1, G2 = (h.cpu() != 0), (out.cpu() != 0)
+    flips = int((G1 != (ref_h != 0)).sum() + (G2 != (ref != 0)).sum())
+    assert flips <= max(2, x.numel() // 20000), flips
     xo, w1o, w2o = (t.clone().requires_grad_(True) for t in (x, w1, w2))
-    ref = orc.residual_block(xo, w1o, w2o)
-    (ref * wgt).sum().backward()
+    lin = (F.conv3d(F.conv3d(xo, w1o, padding=1) * G1, w2o, padding=1) + xo) * G2
+    (lin * wgt).sum().backward()
+    dx, dw1, dw2 = o.residual_backward(geom, xd, h, out, w1d, w2d, wgt.cuda())
+    check(tag + " grad_x", dx, xo.grad, 2e-5)
+    check(tag + " grad_w1", dw1, w1o.grad, 2e-5)
+    check(tag + " grad_w2", dw2, w2o.grad, 2e-5)
+    # the autograd node is the same two calls
     xg, w1g, w2g = (t.cuda().requires_grad_(True) for t in (x, w1, w2))
-    out = cva.loop.ResidualBlockFn.apply(xg, w1g, w2g)
-    check(f"block M={M} {shape} out", out, ref, 1e-5)
-    (out * wgt.cuda()).sum().backward()
-    check(f"block M={M} {shape} grad_x", xg.grad, xo.grad, 1e-4)
-    check(f"block M={M} {shape} grad_w1", w1g.grad, w1o.grad, 1e-4)
-    check(f"block M={M} {shape} grad_w2", w2g.grad, w2o.grad, 1e-4)
+    out2 = cva.loop.ResidualBlockFn.apply(xg, w1g, w2g)
+    (out2 * wgt.cuda()).sum().backward()
+    assert torch.equal(out2.detach(), out) and torch.equal(xg.grad, dx) and torch.equal(w1g.grad, dw1)
