@@ -113,6 +113,9 @@ size_t cdl_mfma_synthesis_ws_floats(const cdl_geom *g);
 // matrix-core analysis (cdl_analysis_mfma.hip), same convention
 // cdl_dense_mfma.hip: many-channel unit-stride convolution (C >= 16 on both sides), analysis or synthesis role
 size_t cdl_dense_ws_floats(const cdl_geom *g, int transpose);
+size_t cdl_dense_wgrad_ws_floats(const cdl_geom *g);
+int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                    float *ws, size_t ws_floats, void *stream);
 int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float *in_gate, const float *w,
                    float alpha, const float *add, const float *add_gate, const float *mask, const float *sub,
                    const float *tau, int relu, float *out, float *ws, size_t ws_floats, void *stream);

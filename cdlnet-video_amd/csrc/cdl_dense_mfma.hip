@@ -271,3 +271,227 @@ int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float
                       g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT};
     return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Filter gradient of the dense convolution (3x3 in-plane taps, any Pd):
+//     dW[o, i, kd, ki, kj] = alpha * sum_{n,d,y,x} G[n,o,d,y,x] [gate != 0] * X[n,i,d+kd-pd,y+ki-1,x+kj-1]
+// Per tap a (o) x (k = pixel) by (k = pixel) x (i) product: A = 8 consecutive pixels of one G channel, B = the same
+// 8 pixels of one X channel shifted by the tap.  Workgroup (8 waves): a 4 x 32 tile of pixels at one (n, d), 64
+// output x 64 input channels, the 9 in-plane taps of ONE kd (blockIdx.y); wave = (32x32 channel pair, taps 0-4 or
+// 5-8), 5 accumulator tiles.  G and X tiles sit in LDS as bf16 hi/lo rows ([channel][pixel], padded strides);
+// the kj = 0 / 2 operands are the aligned 16-byte row chunk funnel-shifted by one element with the neighbouring
+// dword (v_alignbyte), so no shifted copies are stored.  A workgroup walks tiles blockIdx.x, +gridDim.x, ...
+// accumulating in registers and writes one partial bank; k_dense_wfold adds the partials in a fixed order.
+namespace {
+
+constexpr int WTX = 32, WTY = 4, WNT = 512;
+constexpr int GST = WTX * WTY + 8;           // elements per G channel row (16-byte pad: banks)
+constexpr int XCOLS = WTX + 16;              // 8 halo slots either side keep every chunk 16-byte aligned
+constexpr int XST = (WTY + 2) * XCOLS + 8;   // elements per X channel
+constexpr int WG_MAX = 170;                  // workgroups per kd group (x Pd groups ~ two rounds of 256 CUs)
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo)
+{
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        a[e] = hh;
+        b[e] = (__bf16)(v[e] - (float)hh);
+    }
+    hi = __builtin_bit_cast(uint4, a);
+    lo = __builtin_bit_cast(uint4, b);
+}
+
+// the 8 elements starting one element before (kj == 0) / after (kj == 2) the aligned chunk c at element e0
+__device__ __forceinline__ uint4 shifted(const __bf16 *plane, int e0, uint4 c, int kj)
+{
+    if (kj == 1) return c;
+    if (kj == 0) {
+        const unsigned p = *reinterpret_cast<const unsigned *>(plane + e0 - 2);
+        return uint4{__builtin_amdgcn_alignbyte(c.x, p, 2), __builtin_amdgcn_alignbyte(c.y, c.x, 2),
+                     __builtin_amdgcn_alignbyte(c.z, c.y, 2), __builtin_amdgcn_alignbyte(c.w, c.z, 2)};
+    }
+    const unsigned nx = *reinterpret_cast<const unsigned *>(plane + e0 + 8);
+    return uint4{__builtin_amdgcn_alignbyte(c.y, c.x, 2), __builtin_amdgcn_alignbyte(c.z, c.y, 2),
+                 __builtin_amdgcn_alignbyte(c.w, c.z, 2), __builtin_amdgcn_alignbyte(nx, c.w, 2)};
+}
+
+__global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G, const float *__restrict__ gate,
+                                                     const float *__restrict__ X, float *__restrict__ partial,
+                                                     int N, int O, int I, int D, int H, int W, int Pd, int tilesX,
+                                                     int tilesY, int ntiles)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *gh = reinterpret_cast<__bf16 *>(smem);         // [64][GST]
+    __bf16 *gl = gh + 64 * GST;
+    __bf16 *xh = gl + 64 * GST;                            // [64][XST]
+    __bf16 *xl = xh + 64 * XST;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    const int Ro = (wv >> 1) & 1, Ri = wv & 1, tap0 = (wv >> 2) ? 5 : 0, ntap = (wv >> 2) ? 4 : 5;
+    const int kd = blockIdx.y, o0 = 64 * blockIdx.z, pd = Pd / 2;
+    const size_t plane = (size_t)H * W;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tx = b % tilesX; b /= tilesX;
+        const int ty = b % tilesY; b /= tilesY;
+        const int d = b % D, n = b / D;
+        const int dz = d + kd - pd;
+        if (dz < 0 || dz >= D) continue;                   // uniform: the tap plane is zero padding
+        __syncthreads();
+        for (int it = threadIdx.x; it < 64 * WTY * 4; it += WNT) {
+            const int cg = it & 3, row = (it >> 2) & 3, o = it >> 4;
+            const int y = ty * WTY + row, x0 = tx * WTX + cg * 8, oo = o0 + o;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            if (oo < O && y < H) {
+                const size_t base = (((size_t)n * O + oo) * D + d) * plane + (size_t)y * W + x0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (x0 + e < W) {
+                        const float val = G[base + e];
+                        v[e] = (gate && gate[base + e] == 0.0f) ? 0.0f : val;
+                    }
+            }
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *reinterpret_cast<uint4 *>(gh + o * GST + row * WTX + cg * 8) = hi;
+            *reinterpret_cast<uint4 *>(gl + o * GST + row * WTX + cg * 8) = lo;
+        }
+        for (int it = threadIdx.x; it < 64 * (WTY + 2) * 6; it += WNT) {
+            const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
+            const int y = ty * WTY - 1 + row, x0 = tx * WTX - 8 + cg * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            if (i < I && y >= 0 && y < H) {
+                const float *src = X + (((size_t)n * I + i) * D + dz) * plane + (size_t)y * W;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int xx = x0 + e;
+                    if (xx >= 0 && xx < W) v[e] = src[xx];
+                }
+            }
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *reinterpret_cast<uint4 *>(xh + i * XST + row * XCOLS + cg * 8) = hi;
+            *reinterpret_cast<uint4 *>(xl + i * XST + row * XCOLS + cg * 8) = lo;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < WTY * WTX / 16; ++ks) {
+            const int r = ks >> 1, c0 = 16 * (ks & 1) + 8 * h;
+            const int ga = (32 * Ro + l32) * GST + r * WTX + c0;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gh + ga));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gl + ga));
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t < ntap) {                            // wave-uniform
+                    const int tap = tap0 + t, ki = tap / 3, kj = tap - 3 * ki;
+                    const int e0 = (32 * Ri + l32) * XST + (r + ki) * XCOLS + 8 + c0;
+                    const uint4 ch = *reinterpret_cast<const uint4 *>(xh + e0);
+                    const uint4 cl = *reinterpret_cast<const uint4 *>(xl + e0);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, shifted(xh, e0, ch, kj));
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, shifted(xl, e0, cl, kj));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial[((og * Pd + kd) * nwg + wg) * 9 + tap][o_local 64][i 64]
+    float *dst = partial + ((size_t)(blockIdx.z * Pd + kd) * gridDim.x + blockIdx.x) * 9 * 4096;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        if (t < ntap) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ol = 32 * Ro + 8 * (v >> 2) + 4 * h + (v & 3);
+                dst[(size_t)(tap0 + t) * 4096 + ol * 64 + 32 * Ri + l32] = acc[t][v];
+            }
+        }
+    }
+}
+
+// one thread per (o, kd, tap, i), i fastest (coalesced partial reads); fixed summation order
+__global__ __launch_bounds__(256) void k_dense_wfold(const float *__restrict__ partial, float *__restrict__ dw,
+                                                     float alpha, int O, int I, int Pd, int nwg)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * Pd * 9 * 64) return;
+    const int i = idx & 63;
+    int r = idx >> 6;
+    const int tap = r % 9; r /= 9;
+    const int kd = r % Pd, o = r / Pd;
+    if (i >= I) return;
+    const int og = o >> 6, ol = o & 63;
+    const float *src = partial + ((size_t)(og * Pd + kd) * nwg * 9 + tap) * 4096 + ol * 64 + i;
+    float s = 0.0f;
+    for (int wg = 0; wg < nwg; ++wg) s += src[(size_t)wg * 9 * 4096];
+    dw[(((size_t)o * I + i) * Pd + kd) * 9 + tap] = alpha * s;
+}
+
+struct WgradPlan {
+    int tilesX, tilesY, ntiles, nwg, ogroups;
+    size_t ws;
+};
+
+bool wgrad_plan(const cdl_geom *g, WgradPlan *p)
+{
+    if (g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
+    if (g->Ph != 3 || g->Pw != 3 || !(g->Pd & 1)) return false;
+    if (g->pd != g->Pd / 2 || g->ph != 1 || g->pw != 1) return false;
+    if (g->C < 16 || g->C > 64 || g->M < 16) return false;
+    p->tilesX = (g->W + WTX - 1) / WTX;
+    p->tilesY = (g->H + WTY - 1) / WTY;
+    const size_t nt = (size_t)g->N * g->D * p->tilesX * p->tilesY;
+    if (nt >= ((size_t)1 << 31) || nt < 8) return false;   // tiny launches: the per-filter-row kernel
+    p->ntiles = (int)nt;
+    p->nwg = p->ntiles < WG_MAX ? p->ntiles : WG_MAX;
+    p->ogroups = (g->M + 63) / 64;
+    if (p->ogroups > 65535 || g->Pd > 65535) return false;
+    p->ws = (size_t)p->ogroups * g->Pd * p->nwg * 9 * 4096;
+    return true;
+}
+
+}  // namespace
+
+size_t cdl_dense_wgrad_ws_floats(const cdl_geom *g)
+{
+    WgradPlan p;
+    return wgrad_plan(g, &p) ? p.ws : 0;
+}
+
+// dw (M,C,Pd,3,3) = alpha * correlation of F (N,M,..) [gate != 0] with x (N,C,..); CDL_EUNSUPPORTED: fall back
+int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                    float *ws, size_t ws_floats, void *stream)
+{
+    WgradPlan p;
+    if (!wgrad_plan(g, &p)) return CDL_EUNSUPPORTED;
+    if (!ws || ws_floats < p.ws) return CDL_EUNSUPPORTED;
+    static bool attr_done = false;
+    const size_t lds = (size_t)(64 * GST + 64 * XST) * 2 * sizeof(__bf16);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_dense_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    k_dense_wgrad<<<dim3((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups), WNT, lds, S(stream)>>>(
+        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles);
+    CDL_LAUNCH_CHECK();
+    const int nout = g->M * g->Pd * 9 * 64;
+    k_dense_wfold<<<(nout + 255) / 256, 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -738,7 +738,9 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
     const size_t tiles = (size_t)g->N * (g->D / g->sd) * ((g->W / g->sw + 63) / 64) * ((g->H / g->sh + 31) / 32);
     const size_t by_tiles = tiles <= 4096 ? tiles * total : 0;                   // <= a few tens of MB
     const size_t by_mfma = mfma_wgrad_enabled() ? cdl_mfma_wgrad_ws_floats(g) : 0;  // cdl_wgrad_mfma.hip
-    const size_t a = by_rows > by_tiles ? by_rows : by_tiles;
+    size_t a = by_rows > by_tiles ? by_rows : by_tiles;
+    const size_t by_dense = mfma_dense_enabled() ? cdl_dense_wgrad_ws_floats(g) : 0;     // cdl_dense_mfma.hip
+    if (by_dense > a) a = by_dense;
     return a > by_mfma ? a : by_mfma;
 }
 
@@ -748,6 +750,10 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
     if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
     if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
     if (!getenv("CDL_NO_TILED")) {
+        if (mfma_dense_enabled()) {
+            const int rcd = cdl_dense_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
+            if (rcd != CDL_EUNSUPPORTED) return rcd;
+        }
         if (mfma_wgrad_enabled()) {
             const int rcm = cdl_mfma_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
             if (rcm != CDL_EUNSUPPORTED) return rcm;

@@ -110,6 +110,7 @@ def test_filter_and_threshold_grads(N, C, M, sp, P, s, path, monkeypatch):
     """Filter gradients through the matrix-core kernel (default where it exists: >= 64 tiles of 64 x 32 code
     pixels; smaller launches fall through) and through the fp32 VALU kernels (CDL_MFMA_WGRAD=0)."""
     monkeypatch.setenv("CDL_MFMA_WGRAD", "1" if path == "mfma" else "0")
+    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=2)
     pad = tuple(p // 2 for p in P)
