@@ -10,8 +10,10 @@
 // Workgroup (512 threads, 8 waves): a 32 x 16 tile of output pixels at one depth, MT <= 2 tiles of 32 output
 // channels (more: blockIdx.y); wave w owns rows 2w, 2w+1.  The k loop runs over stages = (16-channel chunk, kd):
 // each stage parks the (16+Ph-1) x (32+Pw-1) x 16-channel input window (fp32 -> bf16 hi + lo) and that stage's
-// Ph*Pw weight fragments in LDS (75 KB for 3x3: two workgroups per CU overlap each other's staging), then issues
-// Ph*Pw taps x 2 rows x MT x 3 MFMAs (split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// Ph*Pw weight fragments in LDS (75 KB for 3x3), then issues Ph*Pw taps x 2 rows x MT x 3 MFMAs (split-bf16:
+// hi*hi + hi*lo + lo*hi, fp32 accumulate); the next stage's global loads are in flight in registers meanwhile
+// (two co-resident workgroups with unpipelined staging measured 0.22 ms per 64->64 3x3x3 convolution of a
+// 16 x 128 x 128 volume, 31 % of the MFMA rate).
 // Epilogue straight from the accumulators (lanes l32 = 32 consecutive x: 128-byte segments):
 //     v = alpha * acc;  v *= mask;  v += add [where add_gate != 0];  v -= sub;  v = ST(v, tau);  v = max(v, 0)
 // which covers the analysis role (add = zin, tau), the synthesis role (transposed + flipped weights, input gate,
@@ -20,6 +22,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -35,6 +38,7 @@ struct DenseArgs {
     int relu;
     float *out;
     int N, I, O, D, H, W, Pd, Ph, Pw, tilesX, tilesY, NCC, MTT;
+    int dbg;                                               // CDL_DENSE_DEBUG (timing probes only): 1 no global loads, 2 no MFMAs, 4 no epilogue
 };
 
 // frags[(((cc*Pd + kd)*taps + tap)*MTT + R)*2 + {hi,lo}][64]: lane (l32, h) holds output channel o = 32R + l32,
@@ -69,12 +73,12 @@ __global__ void k_dense_prep(const float *__restrict__ w, uint4 *__restrict__ fr
 }
 
 template <int MT>
-__global__ __launch_bounds__(DNT, 2) void k_dense(DenseArgs a)
+__global__ __launch_bounds__(DNT) void k_dense(DenseArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int XH = DTY + a.Ph - 1, XW = DTX + a.Pw - 1, taps = a.Ph * a.Pw;
     const int npix = XH * XW;
-    uint4 *xh = reinterpret_cast<uint4 *>(smem);           // [npix][2 halves] 8 bf16 each (hi parts)
+    uint4 *xh = reinterpret_cast<uint4 *>(smem);           // [2 halves][npix] 8 bf16 each (hi parts)
     uint4 *xl = xh + (size_t)npix * 2;                     // lo parts
     uint4 *wl = xl + (size_t)npix * 2;                     // [taps][MT][2][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
@@ -94,71 +98,126 @@ __global__ __launch_bounds__(DNT, 2) void k_dense(DenseArgs a)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[rr][R][v] = 0.0f;
 
-    const int stages = a.NCC * a.Pd;
-#pragma unroll 1
-    for (int st = 0; st < stages; ++st) {
-        const int cc = st / a.Pd, kd = st % a.Pd;
+    // Stages = (16-channel chunk) x (kd whose plane exists at this depth).  The next stage's global loads (input
+    // window items and weight fragments) are issued into registers before the current stage's MFMAs and parked in
+    // LDS after them: one workgroup per CU, the loads fly under ~3 us of matrix work instead of in front of it.
+    const int kd_lo = pd - zd > 0 ? pd - zd : 0;
+    const int kd_hi = a.D - 1 - zd + pd < a.Pd - 1 ? a.D - 1 - zd + pd : a.Pd - 1;
+    const int nkd = kd_hi - kd_lo + 1, nst = a.NCC * nkd;
+    const int nW = taps * MT * 128;
+    constexpr int NIT = 3, NWR = 5;                        // items / fragments per thread held in registers
+    float pin[NIT][8], pgt[NIT][8];
+    u32x4 wreg[NWR];                                       // native vectors: a HIP uint4 array went to scratch
+    int st_frag = 0;                                       // (cc * Pd + kd) of the stage held in the registers
+
+    auto load_stage = [&](int s) {
+        const int cc = s / nkd, kd = kd_lo + s - cc * nkd;
         const int d = zd - pd + kd;
-        if (d < 0 || d >= a.D) continue;                   // uniform: a plane of zero padding
-        __syncthreads();                                   // the previous stage's readers are done
-        // input window: (pixel, half) items, consecutive threads on consecutive x
-        for (int it = threadIdx.x; it < npix * 2; it += DNT) {
-            const int half = it / npix, pix = it - half * npix;
+        st_frag = cc * a.Pd + kd;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = threadIdx.x + j * DNT;
+            const int half = it >= npix ? 1 : 0, pix = it - half * npix;
             const int row = pix / XW, col = pix - row * XW;
             const int yy = ty * DTY - ph + row, xx = tx * DTX - pw + col;
             const int c0 = DKC * cc + 8 * half;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)yy * a.W + xx;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e < a.I) v[e] = a.x[base + e * slab];
-                if (a.in_gate) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (c0 + e < a.I && a.in_gate[base + e * slab] == 0.0f) v[e] = 0.0f;
-                }
-            }
-            bf16x8 hi, lo;
+            const bool inb = it < npix * 2 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)(inb ? yy : 0) * a.W + (inb ? xx : 0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const __bf16 hh = (__bf16)v[e];
-                hi[e] = hh;
-                lo[e] = (__bf16)(v[e] - (float)hh);
+                const bool ok = inb && c0 + e < a.I && !(a.dbg & 1);
+                pin[j][e] = ok ? a.x[base + e * slab] : 0.0f;
+                pgt[j][e] = (ok && a.in_gate) ? a.in_gate[base + e * slab] : 1.0f;
             }
-            xh[pix * 2 + half] = __builtin_bit_cast(uint4, hi);
-            xl[pix * 2 + half] = __builtin_bit_cast(uint4, lo);
         }
-        // this stage's weight fragments for channel tiles r0 .. r0+MT-1
-        for (int i = threadIdx.x; i < taps * MT * 128; i += DNT) {
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int i = (threadIdx.x + j * DNT < nW && !(a.dbg & 1)) ? threadIdx.x + j * DNT : 0;   // unconditional: stays in VGPRs
             const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
-            wl[i] = a.frags[((size_t)(st * taps + tap) * a.MTT + r0) * 128 + rem];
+            wreg[j] = reinterpret_cast<const u32x4 *>(a.frags)[((size_t)(st_frag * taps + tap) * a.MTT + r0) * 128 + rem];
         }
-        __syncthreads();
-        int ki = 0, kj = 0;
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = threadIdx.x + j * DNT;
+            if (it < npix * 2) {
+                const int half = it >= npix ? 1 : 0, pix = it - half * npix;
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = pgt[j][e] == 0.0f ? 0.0f : pin[j][e];
+                    const __bf16 hh = (__bf16)v;
+                    hi[e] = hh;
+                    lo[e] = (__bf16)(v - (float)hh);
+                }
+                xh[half * npix + pix] = __builtin_bit_cast(uint4, hi);    // [half][pixel]: a 16-lane group reads
+                xl[half * npix + pix] = __builtin_bit_cast(uint4, lo);    // 256 contiguous bytes, no bank conflict
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int i = threadIdx.x + j * DNT;
+            if (i < nW) reinterpret_cast<u32x4 *>(wl)[i] = wreg[j];
+        }
+        for (int i = threadIdx.x + NWR * DNT; i < nW; i += DNT) {      // 5 x 5 taps: the tail goes straight through
+            const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
+            wl[i] = a.frags[((size_t)(st_frag * taps + tap) * a.MTT + r0) * 128 + rem];
+        }
+    };
+
+    load_stage(0);
 #pragma unroll 1
-        for (int tap = 0; tap < taps; ++tap) {
-            bf16x8 bh[2], bl[2];
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();                                   // the previous stage's readers are done
+        store_stage();
+        __syncthreads();
+        if (st + 1 < nst) load_stage(st + 1);
+        // software-pipelined over the taps: the next tap's 8 operand reads are in flight under this tap's 12 MFMAs
+        // (reading and then waiting inside one iteration exposed ~3 LDS latencies per 12 MFMAs: 31 % of the MFMA rate)
+        bf16x8 bh[2], bl[2], ah[MT], al[MT];
+        auto read_tap = [&](int tap, int ki, int kj, bf16x8 (&qbh)[2], bf16x8 (&qbl)[2], bf16x8 (&qah)[MT], bf16x8 (&qal)[MT]) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int pix = (2 * wv + rr + ki) * XW + l32 + kj;
-                bh[rr] = __builtin_bit_cast(bf16x8, xh[pix * 2 + h]);
-                bl[rr] = __builtin_bit_cast(bf16x8, xl[pix * 2 + h]);
+                qbh[rr] = __builtin_bit_cast(bf16x8, xh[h * npix + pix]);
+                qbl[rr] = __builtin_bit_cast(bf16x8, xl[h * npix + pix]);
             }
 #pragma unroll
             for (int R = 0; R < MT; ++R) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + lane]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + 64 + lane]);
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[rr], acc[rr][R], 0, 0, 0);
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[rr], acc[rr][R], 0, 0, 0);
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[rr], acc[rr][R], 0, 0, 0);
-                }
+                qah[R] = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + lane]);
+                qal[R] = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + 64 + lane]);
             }
+        };
+        read_tap(0, 0, 0, bh, bl, ah, al);
+        int ki = 0, kj = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < ((a.dbg & 2) ? 0 : taps); ++tap) {
             if (++kj == a.Pw) { kj = 0; ++ki; }
+            bf16x8 nbh[2], nbl[2], nah[MT], nal[MT];
+            const int nt = tap + 1 < taps ? tap + 1 : tap;         // last iteration: a harmless re-read
+            read_tap(nt, tap + 1 < taps ? ki : 0, tap + 1 < taps ? kj : 0, nbh, nbl, nah, nal);
+            __builtin_amdgcn_sched_barrier(0);             // keep the reads above the MFMAs (the scheduler sinks them)
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[R], bh[rr], acc[rr][R], 0, 0, 0);
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bl[rr], acc[rr][R], 0, 0, 0);
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bh[rr], acc[rr][R], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) { bh[rr] = nbh[rr]; bl[rr] = nbl[rr]; }
+#pragma unroll
+            for (int R = 0; R < MT; ++R) { ah[R] = nah[R]; al[R] = nal[R]; }
         }
     }
 
@@ -173,7 +232,7 @@ __global__ __launch_bounds__(DNT, 2) void k_dense(DenseArgs a)
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = ty * DTY + 2 * wv + rr;
-        if (y >= a.H || x >= a.W) continue;
+        if (y >= a.H || x >= a.W || (a.dbg & 4)) continue;
         const int pix = y * a.W + x;
 #pragma unroll
         for (int R = 0; R < MT; ++R) {
@@ -268,7 +327,8 @@ int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float
                                                               transpose);
     CDL_LAUNCH_CHECK();
     const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, relu, out,
-                      g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT};
+                      g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT,
+                      getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0};
     return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));
 }
 
@@ -288,7 +348,7 @@ constexpr int WTX = 32, WTY = 4, WNT = 512;
 constexpr int GST = WTX * WTY + 8;           // elements per G channel row (16-byte pad: banks)
 constexpr int XCOLS = WTX + 16;              // 8 halo slots either side keep every chunk 16-byte aligned
 constexpr int XST = (WTY + 2) * XCOLS + 8;   // elements per X channel
-constexpr int WG_MAX = 170;                  // workgroups per kd group (x Pd groups ~ two rounds of 256 CUs)
+constexpr int WG_TOTAL = 255;                // workgroups over all (kd, channel-group) pairs: one round of the 256 CUs
 
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo)
 {
@@ -320,7 +380,7 @@ __device__ __forceinline__ uint4 shifted(const __bf16 *plane, int e0, uint4 c, i
 __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G, const float *__restrict__ gate,
                                                      const float *__restrict__ X, float *__restrict__ partial,
                                                      int N, int O, int I, int D, int H, int W, int Pd, int tilesX,
-                                                     int tilesY, int ntiles)
+                                                     int tilesY, int ntiles, int vec)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *gh = reinterpret_cast<__bf16 *>(smem);         // [64][GST]
@@ -338,75 +398,139 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
 
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // The next tile's global loads are issued into registers before the current tile's MFMAs and parked in LDS
+    // after them (one batch of loads in flight per tile instead of a chain of dependent round trips).
+    constexpr int NG = 64 * WTY * 4 / WNT, NX = (64 * (WTY + 2) * 6 + WNT - 1) / WNT;     // 2 and 5 items per thread
+    float pg[NG][8], pgg[NG][8], px[NX][8];
+    auto tile_valid = [&](int t) { const int d = (t / (tilesX * tilesY)) % D; return d + kd - pd >= 0 && d + kd - pd < D; };
+    auto next_tile = [&](int t) { while (t < ntiles && !tile_valid(t)) t += gridDim.x; return t; };
+    auto load_tile = [&](int tile) {
         int b = tile;
         const int tx = b % tilesX; b /= tilesX;
         const int ty = b % tilesY; b /= tilesY;
         const int d = b % D, n = b / D;
         const int dz = d + kd - pd;
-        if (dz < 0 || dz >= D) continue;                   // uniform: the tap plane is zero padding
-        __syncthreads();
-        for (int it = threadIdx.x; it < 64 * WTY * 4; it += WNT) {
+        // uniform bases + 32-bit offsets inside one sample (the plan bounds channels * D * H * W below 2^31)
+        const float *Gt = G + ((size_t)n * O * D + d) * plane;
+        const float *Tt = gate ? gate + ((size_t)n * O * D + d) * plane : nullptr;
+        const float *Xt = X + ((size_t)n * I * D + dz) * plane;
+        const int cstride = D * (int)plane;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int it = threadIdx.x + j * WNT;
             const int cg = it & 3, row = (it >> 2) & 3, o = it >> 4;
             const int y = ty * WTY + row, x0 = tx * WTX + cg * 8, oo = o0 + o;
+            const bool rowok = oo < O && y < H;
+            const int off = rowok ? oo * cstride + y * W + x0 : 0;
+            if (vec) {                                     // 16-byte loads: W % 4 == 0, aligned bases, x0 % 8 == 0
+                const bool ok = rowok && x0 + 8 <= W;      // W % 4 == 0 and x0 % 8 == 0: a chunk is all in or all out ...
+                const bool ok2 = rowok && x0 + 4 <= W;     // ... except its first half at the right edge
+                const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f}, one4 = {1.0f, 1.0f, 1.0f, 1.0f};
+                const float4 a = ok2 ? *reinterpret_cast<const float4 *>(Gt + off) : z4;
+                const float4 c = ok ? *reinterpret_cast<const float4 *>(Gt + off + 4) : z4;
+                const float4 ga = (ok2 && Tt) ? *reinterpret_cast<const float4 *>(Tt + off) : one4;
+                const float4 gc = (ok && Tt) ? *reinterpret_cast<const float4 *>(Tt + off + 4) : one4;
+                pg[j][0] = a.x; pg[j][1] = a.y; pg[j][2] = a.z; pg[j][3] = a.w;
+                pg[j][4] = c.x; pg[j][5] = c.y; pg[j][6] = c.z; pg[j][7] = c.w;
+                pgg[j][0] = ga.x; pgg[j][1] = ga.y; pgg[j][2] = ga.z; pgg[j][3] = ga.w;
+                pgg[j][4] = gc.x; pgg[j][5] = gc.y; pgg[j][6] = gc.z; pgg[j][7] = gc.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = rowok && x0 + e < W;
+                    pg[j][e] = ok ? Gt[off + e] : 0.0f;
+                    pgg[j][e] = (ok && Tt) ? Tt[off + e] : 1.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int it = threadIdx.x + j * WNT;
+            const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
+            const int y = ty * WTY - 1 + row, x0 = tx * WTX - 8 + cg * 8;
+            const bool rowok = i < I && y >= 0 && y < H;       // i >= 64 (items past the end) fail i < I <= 64
+            const int off = rowok ? i * cstride + y * W : 0;
+            const bool halo = cg == 0 || cg == 5;              // only the element next to the tile is read
+            if (vec) {
+                const bool ok2 = rowok && !halo && x0 + 4 <= W, ok = rowok && !halo && x0 + 8 <= W;
+                const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float4 a = ok2 ? *reinterpret_cast<const float4 *>(Xt + off + x0) : z4;
+                const float4 c = ok ? *reinterpret_cast<const float4 *>(Xt + off + x0 + 4) : z4;
+                const int xe = cg == 0 ? x0 + 7 : x0;
+                const float edge = (rowok && halo && xe >= 0 && xe < W) ? Xt[off + xe] : 0.0f;
+                px[j][0] = cg == 5 ? edge : a.x; px[j][1] = a.y; px[j][2] = a.z; px[j][3] = a.w;
+                px[j][4] = c.x; px[j][5] = c.y; px[j][6] = c.z; px[j][7] = cg == 0 ? edge : c.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int xx = x0 + e;
+                    const bool need = !halo || (cg == 0 ? e == 7 : e == 0);
+                    px[j][e] = (rowok && need && xx >= 0 && xx < W) ? Xt[off + xx] : 0.0f;
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int it = threadIdx.x + j * WNT;
+            const int cg = it & 3, row = (it >> 2) & 3, o = it >> 4;
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-            if (oo < O && y < H) {
-                const size_t base = (((size_t)n * O + oo) * D + d) * plane + (size_t)y * W + x0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (x0 + e < W) {
-                        const float val = G[base + e];
-                        v[e] = (gate && gate[base + e] == 0.0f) ? 0.0f : val;
-                    }
-            }
+            for (int e = 0; e < 8; ++e) v[e] = pgg[j][e] == 0.0f ? 0.0f : pg[j][e];
             uint4 hi, lo;
             split8(v, hi, lo);
             *reinterpret_cast<uint4 *>(gh + o * GST + row * WTX + cg * 8) = hi;
             *reinterpret_cast<uint4 *>(gl + o * GST + row * WTX + cg * 8) = lo;
         }
-        for (int it = threadIdx.x; it < 64 * (WTY + 2) * 6; it += WNT) {
-            const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
-            const int y = ty * WTY - 1 + row, x0 = tx * WTX - 8 + cg * 8;
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-            if (i < I && y >= 0 && y < H) {
-                const float *src = X + (((size_t)n * I + i) * D + dz) * plane + (size_t)y * W;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int xx = x0 + e;
-                    if (xx >= 0 && xx < W) v[e] = src[xx];
-                }
+        for (int j = 0; j < NX; ++j) {
+            const int it = threadIdx.x + j * WNT;
+            if (it < 64 * (WTY + 2) * 6) {
+                const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
+                uint4 hi, lo;
+                split8(px[j], hi, lo);
+                *reinterpret_cast<uint4 *>(xh + i * XST + row * XCOLS + cg * 8) = hi;
+                *reinterpret_cast<uint4 *>(xl + i * XST + row * XCOLS + cg * 8) = lo;
             }
-            uint4 hi, lo;
-            split8(v, hi, lo);
-            *reinterpret_cast<uint4 *>(xh + i * XST + row * XCOLS + cg * 8) = hi;
-            *reinterpret_cast<uint4 *>(xl + i * XST + row * XCOLS + cg * 8) = lo;
         }
+    };
+
+    int tile = next_tile(blockIdx.x);
+    if (tile < ntiles) load_tile(tile);
+#pragma unroll 1
+    while (tile < ntiles) {
+        __syncthreads();                                   // the previous tile's readers are done
+        store_tile();
         __syncthreads();
+        tile = next_tile(tile + gridDim.x);
+        if (tile < ntiles) load_tile(tile);
 #pragma unroll 1
         for (int ks = 0; ks < WTY * WTX / 16; ++ks) {
             const int r = ks >> 1, c0 = 16 * (ks & 1) + 8 * h;
             const int ga = (32 * Ro + l32) * GST + r * WTX + c0;
             const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gh + ga));
             const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gl + ga));
+            bf16x8 bh[5], bl[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                if (t < ntap) {                            // wave-uniform
-                    const int tap = tap0 + t, ki = tap / 3, kj = tap - 3 * ki;
-                    const int e0 = (32 * Ri + l32) * XST + (r + ki) * XCOLS + 8 + c0;
-                    const uint4 ch = *reinterpret_cast<const uint4 *>(xh + e0);
-                    const uint4 cl = *reinterpret_cast<const uint4 *>(xl + e0);
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, shifted(xh, e0, ch, kj));
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, shifted(xl, e0, cl, kj));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-                }
+                const int tap = tap0 + (t < ntap ? t : 0), ki = tap / 3, kj = tap - 3 * ki;   // t >= ntap: unused copy
+                const int e0 = (32 * Ri + l32) * XST + (r + ki) * XCOLS + 8 + c0;
+                const uint4 ch = *reinterpret_cast<const uint4 *>(xh + e0);
+                const uint4 cl = *reinterpret_cast<const uint4 *>(xl + e0);
+                bh[t] = __builtin_bit_cast(bf16x8, shifted(xh, e0, ch, kj));
+                bl[t] = __builtin_bit_cast(bf16x8, shifted(xl, e0, cl, kj));
             }
+            // term-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
         }
     }
     // partial[((og * Pd + kd) * nwg + wg) * 9 + tap][o_local 64][i 64]
@@ -423,22 +547,24 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
     }
 }
 
-// one thread per (o, kd, tap, i), i fastest (coalesced partial reads); fixed summation order
+// one 64-thread row per (o, kd, tap) and i, four rows per workgroup summing interleaved slices of the partial
+// banks (a serial loop over all of them was latency bound), combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void k_dense_wfold(const float *__restrict__ partial, float *__restrict__ dw,
                                                      float alpha, int O, int I, int Pd, int nwg)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * Pd * 9 * 64) return;
-    const int i = idx & 63;
-    int r = idx >> 6;
+    __shared__ float part[4][64];
+    const int i = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    int r = blockIdx.x;
     const int tap = r % 9; r /= 9;
     const int kd = r % Pd, o = r / Pd;
-    if (i >= I) return;
     const int og = o >> 6, ol = o & 63;
     const float *src = partial + ((size_t)(og * Pd + kd) * nwg * 9 + tap) * 4096 + ol * 64 + i;
     float s = 0.0f;
-    for (int wg = 0; wg < nwg; ++wg) s += src[(size_t)wg * 9 * 4096];
-    dw[(((size_t)o * I + i) * Pd + kd) * 9 + tap] = alpha * s;
+    for (int wg = slice; wg < nwg; wg += 4) s += src[(size_t)wg * 9 * 4096];
+    part[slice][i] = s;
+    __syncthreads();
+    if (slice == 0 && i < I)
+        dw[(((size_t)o * I + i) * Pd + kd) * 9 + tap] = alpha * (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]);
 }
 
 struct WgradPlan {
@@ -452,14 +578,18 @@ bool wgrad_plan(const cdl_geom *g, WgradPlan *p)
     if (g->Ph != 3 || g->Pw != 3 || !(g->Pd & 1)) return false;
     if (g->pd != g->Pd / 2 || g->ph != 1 || g->pw != 1) return false;
     if (g->C < 16 || g->C > 64 || g->M < 16) return false;
+    const size_t vol = (size_t)g->D * g->H * g->W;
+    if ((size_t)g->M * vol >= ((size_t)1 << 31) || (size_t)g->C * vol >= ((size_t)1 << 31)) return false;
     p->tilesX = (g->W + WTX - 1) / WTX;
     p->tilesY = (g->H + WTY - 1) / WTY;
     const size_t nt = (size_t)g->N * g->D * p->tilesX * p->tilesY;
     if (nt >= ((size_t)1 << 31) || nt < 8) return false;   // tiny launches: the per-filter-row kernel
     p->ntiles = (int)nt;
-    p->nwg = p->ntiles < WG_MAX ? p->ntiles : WG_MAX;
     p->ogroups = (g->M + 63) / 64;
     if (p->ogroups > 65535 || g->Pd > 65535) return false;
+    p->nwg = WG_TOTAL / (g->Pd * p->ogroups);
+    if (p->nwg < 1) p->nwg = 1;
+    if (p->nwg > p->ntiles) p->nwg = p->ntiles;
     p->ws = (size_t)p->ogroups * g->Pd * p->nwg * 9 * 4096;
     return true;
 }
@@ -480,6 +610,8 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
     if (!wgrad_plan(g, &p)) return CDL_EUNSUPPORTED;
     if (!ws || ws_floats < p.ws) return CDL_EUNSUPPORTED;
     static bool attr_done = false;
+    const int vec = (g->W % 4 == 0) && !((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(x) |
+                                           reinterpret_cast<size_t>(gate)) & 15);
     const size_t lds = (size_t)(64 * GST + 64 * XST) * 2 * sizeof(__bf16);
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_dense_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -488,10 +620,9 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
         attr_done = true;
     }
     k_dense_wgrad<<<dim3((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups), WNT, lds, S(stream)>>>(
-        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles);
+        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles, vec);
     CDL_LAUNCH_CHECK();
-    const int nout = g->M * g->Pd * 9 * 64;
-    k_dense_wfold<<<(nout + 255) / 256, 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
+    k_dense_wfold<<<(unsigned)(g->M * g->Pd * 9), 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
     CDL_LAUNCH_CHECK();
     return 0;
 }
