@@ -73,7 +73,7 @@ __global__ void k_dense_prep(const float *__restrict__ w, uint4 *__restrict__ fr
 }
 
 template <int MT>
-__global__ __launch_bounds__(DNT) void k_dense(DenseArgs a)
+__global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd argument = waves per SIMD -> <= 128 VGPRs, two workgroups per CU
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int XH = DTY + a.Ph - 1, XW = DTX + a.Pw - 1, taps = a.Ph * a.Pw;
@@ -98,126 +98,91 @@ __global__ __launch_bounds__(DNT) void k_dense(DenseArgs a)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[rr][R][v] = 0.0f;
 
-    // Stages = (16-channel chunk) x (kd whose plane exists at this depth).  The next stage's global loads (input
-    // window items and weight fragments) are issued into registers before the current stage's MFMAs and parked in
-    // LDS after them: one workgroup per CU, the loads fly under ~3 us of matrix work instead of in front of it.
-    const int kd_lo = pd - zd > 0 ? pd - zd : 0;
-    const int kd_hi = a.D - 1 - zd + pd < a.Pd - 1 ? a.D - 1 - zd + pd : a.Pd - 1;
-    const int nkd = kd_hi - kd_lo + 1, nst = a.NCC * nkd;
-    const int nW = taps * MT * 128;
-    constexpr int NIT = 3, NWR = 5;                        // items / fragments per thread held in registers
-    float pin[NIT][8], pgt[NIT][8];
-    u32x4 wreg[NWR];                                       // native vectors: a HIP uint4 array went to scratch
-    int st_frag = 0;                                       // (cc * Pd + kd) of the stage held in the registers
-
-    auto load_stage = [&](int s) {
-        const int cc = s / nkd, kd = kd_lo + s - cc * nkd;
+    // Two workgroups share a CU (<= 128 VGPRs, 75 KB LDS each), so one's staging and epilogue run under the other's
+    // MFMAs.  CDL_DENSE_DEBUG probes on a 64 -> 64 3x3x3 convolution of a 16 x 128 x 128 volume (0.22 ms): MFMAs
+    // ~0.10 ms (0.07 at the peak rate), staging arithmetic + LDS writes 0.05, exposed global loads 0.05, epilogue
+    // 0.05 when nothing overlaps.  Variants measured at the same 0.22-0.24 ms: one workgroup per CU with the next
+    // stage's loads held in registers under the MFMAs, and that plus a software-pipelined tap loop.
+    const int stages = a.NCC * a.Pd;
+#pragma unroll 1
+    for (int st = 0; st < stages; ++st) {
+        const int cc = st / a.Pd, kd = st % a.Pd;
         const int d = zd - pd + kd;
-        st_frag = cc * a.Pd + kd;
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const int it = threadIdx.x + j * DNT;
-            const int half = it >= npix ? 1 : 0, pix = it - half * npix;
+        if (d < 0 || d >= a.D) continue;                   // uniform: a plane of zero padding
+        __syncthreads();                                   // the previous stage's readers are done
+        // input window: (pixel, half) items, consecutive threads on consecutive x
+        for (int it = threadIdx.x; it < npix * 2; it += DNT) {
+            const int half = it / npix, pix = it - half * npix;
             const int row = pix / XW, col = pix - row * XW;
             const int yy = ty * DTY - ph + row, xx = tx * DTX - pw + col;
             const int c0 = DKC * cc + 8 * half;
-            const bool inb = it < npix * 2 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)(inb ? yy : 0) * a.W + (inb ? xx : 0);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)yy * a.W + xx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < a.I && !(a.dbg & 1)) v[e] = a.x[base + e * slab];
+                if (a.in_gate) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + e < a.I && a.in_gate[base + e * slab] == 0.0f) v[e] = 0.0f;
+                }
+            }
+            bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool ok = inb && c0 + e < a.I && !(a.dbg & 1);
-                pin[j][e] = ok ? a.x[base + e * slab] : 0.0f;
-                pgt[j][e] = (ok && a.in_gate) ? a.in_gate[base + e * slab] : 1.0f;
+                const __bf16 hh = (__bf16)v[e];
+                hi[e] = hh;
+                lo[e] = (__bf16)(v[e] - (float)hh);
+            }
+            xh[half * npix + pix] = __builtin_bit_cast(uint4, hi);    // [half][pixel]: a 16-lane group of a
+            xl[half * npix + pix] = __builtin_bit_cast(uint4, lo);    // ds_read_b128 covers 256 contiguous bytes
+        }
+        // this stage's weight fragments for channel tiles r0 .. r0+MT-1
+        {   // one batch of loads, then the LDS stores (a rolled copy loop was a chain of dependent round trips)
+            constexpr int NWR = 5;
+            const int nW = taps * MT * 128;
+            const u32x4 *fs = reinterpret_cast<const u32x4 *>(a.frags) + (size_t)st * taps * a.MTT * 128;
+            u32x4 wreg[NWR];
+#pragma unroll
+            for (int j = 0; j < NWR; ++j) {
+                const int i = (threadIdx.x + j * DNT < nW && !(a.dbg & 1)) ? threadIdx.x + j * DNT : 0;
+                const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
+                wreg[j] = fs[(unsigned)((tap * a.MTT + r0) * 128 + rem)];
+            }
+#pragma unroll
+            for (int j = 0; j < NWR; ++j)
+                if (threadIdx.x + j * DNT < nW) reinterpret_cast<u32x4 *>(wl)[threadIdx.x + j * DNT] = wreg[j];
+            for (int i = threadIdx.x + NWR * DNT; i < nW; i += DNT) {      // 5 x 5 taps: the tail goes straight through
+                const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
+                reinterpret_cast<u32x4 *>(wl)[i] = fs[(unsigned)((tap * a.MTT + r0) * 128 + rem)];
             }
         }
-#pragma unroll
-        for (int j = 0; j < NWR; ++j) {
-            const int i = (threadIdx.x + j * DNT < nW && !(a.dbg & 1)) ? threadIdx.x + j * DNT : 0;   // unconditional: stays in VGPRs
-            const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
-            wreg[j] = reinterpret_cast<const u32x4 *>(a.frags)[((size_t)(st_frag * taps + tap) * a.MTT + r0) * 128 + rem];
-        }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const int it = threadIdx.x + j * DNT;
-            if (it < npix * 2) {
-                const int half = it >= npix ? 1 : 0, pix = it - half * npix;
-                bf16x8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = pgt[j][e] == 0.0f ? 0.0f : pin[j][e];
-                    const __bf16 hh = (__bf16)v;
-                    hi[e] = hh;
-                    lo[e] = (__bf16)(v - (float)hh);
-                }
-                xh[half * npix + pix] = __builtin_bit_cast(uint4, hi);    // [half][pixel]: a 16-lane group reads
-                xl[half * npix + pix] = __builtin_bit_cast(uint4, lo);    // 256 contiguous bytes, no bank conflict
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NWR; ++j) {
-            const int i = threadIdx.x + j * DNT;
-            if (i < nW) reinterpret_cast<u32x4 *>(wl)[i] = wreg[j];
-        }
-        for (int i = threadIdx.x + NWR * DNT; i < nW; i += DNT) {      // 5 x 5 taps: the tail goes straight through
-            const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
-            wl[i] = a.frags[((size_t)(st_frag * taps + tap) * a.MTT + r0) * 128 + rem];
-        }
-    };
-
-    load_stage(0);
-#pragma unroll 1
-    for (int st = 0; st < nst; ++st) {
-        __syncthreads();                                   // the previous stage's readers are done
-        store_stage();
         __syncthreads();
-        if (st + 1 < nst) load_stage(st + 1);
-        // software-pipelined over the taps: the next tap's 8 operand reads are in flight under this tap's 12 MFMAs
-        // (reading and then waiting inside one iteration exposed ~3 LDS latencies per 12 MFMAs: 31 % of the MFMA rate)
-        bf16x8 bh[2], bl[2], ah[MT], al[MT];
-        auto read_tap = [&](int tap, int ki, int kj, bf16x8 (&qbh)[2], bf16x8 (&qbl)[2], bf16x8 (&qah)[MT], bf16x8 (&qal)[MT]) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int pix = (2 * wv + rr + ki) * XW + l32 + kj;
-                qbh[rr] = __builtin_bit_cast(bf16x8, xh[h * npix + pix]);
-                qbl[rr] = __builtin_bit_cast(bf16x8, xl[h * npix + pix]);
-            }
-#pragma unroll
-            for (int R = 0; R < MT; ++R) {
-                qah[R] = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + lane]);
-                qal[R] = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + 64 + lane]);
-            }
-        };
-        read_tap(0, 0, 0, bh, bl, ah, al);
         int ki = 0, kj = 0;
 #pragma unroll 1
         for (int tap = 0; tap < ((a.dbg & 2) ? 0 : taps); ++tap) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int pix = (2 * wv + rr + ki) * XW + l32 + kj;
+                bh[rr] = __builtin_bit_cast(bf16x8, xh[h * npix + pix]);
+                bl[rr] = __builtin_bit_cast(bf16x8, xl[h * npix + pix]);
+            }
+#pragma unroll
+            for (int R = 0; R < MT; ++R) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + lane]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[(tap * MT + R) * 128 + 64 + lane]);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[rr], acc[rr][R], 0, 0, 0);
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[rr], acc[rr][R], 0, 0, 0);
+                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[rr], acc[rr][R], 0, 0, 0);
+                }
+            }
             if (++kj == a.Pw) { kj = 0; ++ki; }
-            bf16x8 nbh[2], nbl[2], nah[MT], nal[MT];
-            const int nt = tap + 1 < taps ? tap + 1 : tap;         // last iteration: a harmless re-read
-            read_tap(nt, tap + 1 < taps ? ki : 0, tap + 1 < taps ? kj : 0, nbh, nbl, nah, nal);
-            __builtin_amdgcn_sched_barrier(0);             // keep the reads above the MFMAs (the scheduler sinks them)
-#pragma unroll
-            for (int R = 0; R < MT; ++R)
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[R], bh[rr], acc[rr][R], 0, 0, 0);
-#pragma unroll
-            for (int R = 0; R < MT; ++R)
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bl[rr], acc[rr][R], 0, 0, 0);
-#pragma unroll
-            for (int R = 0; R < MT; ++R)
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-                    acc[rr][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bh[rr], acc[rr][R], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) { bh[rr] = nbh[rr]; bl[rr] = nbl[rr]; }
-#pragma unroll
-            for (int R = 0; R < MT; ++R) { ah[R] = nah[R]; al[R] = nal[R]; }
         }
     }
 
@@ -269,7 +234,7 @@ bool dense_plan(const cdl_geom *g, int in, int out, DensePlan *p)
     if (g->Ph > 5 || g->Pw > 5 || !(g->Pd & 1) || !(g->Ph & 1) || !(g->Pw & 1)) return false;
     if (g->pd != g->Pd / 2 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
     const size_t slab = (size_t)g->D * g->H * g->W;
-    if ((size_t)out * slab >= ((size_t)1 << 31)) return false;            // 32-bit offsets inside one sample
+    if ((size_t)out * slab >= ((size_t)1 << 31) || (size_t)in * slab >= ((size_t)1 << 31)) return false;   // 32-bit offsets inside one sample
     p->NCC = (in + DKC - 1) / DKC;
     p->MTT = (out + 31) / 32;
     p->MT = p->MTT >= 2 ? 2 : 1;
@@ -377,10 +342,62 @@ __device__ __forceinline__ uint4 shifted(const __bf16 *plane, int e0, uint4 c, i
                  __builtin_amdgcn_alignbyte(c.w, c.z, 2), __builtin_amdgcn_alignbyte(nx, c.w, 2)};
 }
 
+// the 8 k-steps of one tile for the taps TAP0 .. TAP0+NTAP-1 (compile-time: the operand reads of a k-step -- 2 + 2*NTAP
+// 16-byte chunks and the halo dwords -- are issued together, no branch between them; with run-time taps every
+// shifted operand was a branch and an exposed LDS round trip, 4x the matrix time)
+template <int KJ>
+__device__ __forceinline__ uint4 shifted_c(const __bf16 *plane, int e0, uint4 c)
+{
+    if constexpr (KJ == 1) return c;
+    if constexpr (KJ == 0) {
+        const unsigned p = *reinterpret_cast<const unsigned *>(plane + e0 - 2);
+        return uint4{__builtin_amdgcn_alignbyte(c.x, p, 2), __builtin_amdgcn_alignbyte(c.y, c.x, 2),
+                     __builtin_amdgcn_alignbyte(c.z, c.y, 2), __builtin_amdgcn_alignbyte(c.w, c.z, 2)};
+    }
+    const unsigned nx = *reinterpret_cast<const unsigned *>(plane + e0 + 8);
+    return uint4{__builtin_amdgcn_alignbyte(c.y, c.x, 2), __builtin_amdgcn_alignbyte(c.z, c.y, 2),
+                 __builtin_amdgcn_alignbyte(c.w, c.z, 2), __builtin_amdgcn_alignbyte(nx, c.w, 2)};
+}
+
+template <int TAP, int T, int TAP0, int NTAP>
+__device__ __forceinline__ void read_taps(const __bf16 *xh, const __bf16 *xl, int xbase, bf16x8 (&bh)[5], bf16x8 (&bl)[5])
+{
+    if constexpr (T < NTAP) {
+        constexpr int ki = TAP / 3, kj = TAP % 3;
+        const int e0 = xbase + ki * XCOLS;
+        const uint4 ch = *reinterpret_cast<const uint4 *>(xh + e0);
+        const uint4 cl = *reinterpret_cast<const uint4 *>(xl + e0);
+        bh[T] = __builtin_bit_cast(bf16x8, shifted_c<kj>(xh, e0, ch));
+        bl[T] = __builtin_bit_cast(bf16x8, shifted_c<kj>(xl, e0, cl));
+        read_taps<TAP + 1, T + 1, TAP0, NTAP>(xh, xl, xbase, bh, bl);
+    }
+}
+
+template <int TAP0, int NTAP>
+__device__ __forceinline__ void wgrad_tile(const __bf16 *gh, const __bf16 *gl, const __bf16 *xh, const __bf16 *xl,
+                                           int Ro, int Ri, int l32, int h, f32x16 (&acc)[5])
+{
+#pragma unroll 1
+    for (int ks = 0; ks < WTY * WTX / 16; ++ks) {
+        const int r = ks >> 1, c0 = 16 * (ks & 1) + 8 * h;
+        const int ga = (32 * Ro + l32) * GST + r * WTX + c0;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gh + ga));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gl + ga));
+        bf16x8 bh[5], bl[5];
+        read_taps<TAP0, 0, TAP0, NTAP>(xh, xl, (32 * Ri + l32) * XST + r * XCOLS + 8 + c0, bh, bl);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G, const float *__restrict__ gate,
                                                      const float *__restrict__ X, float *__restrict__ partial,
                                                      int N, int O, int I, int D, int H, int W, int Pd, int tilesX,
-                                                     int tilesY, int ntiles, int vec)
+                                                     int tilesY, int ntiles, int vec, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *gh = reinterpret_cast<__bf16 *>(smem);         // [64][GST]
@@ -497,40 +514,27 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
     };
 
     int tile = next_tile(blockIdx.x);
-    if (tile < ntiles) load_tile(tile);
+    if (tile < ntiles && !(dbg & 1)) load_tile(tile);
+    if (dbg & 1) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pg[j][e] = 1.0f; pgg[j][e] = 1.0f; }
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) px[j][e] = 1.0f;
+    }
 #pragma unroll 1
     while (tile < ntiles) {
         __syncthreads();                                   // the previous tile's readers are done
-        store_tile();
+        if (!(dbg & 4)) store_tile();
         __syncthreads();
         tile = next_tile(tile + gridDim.x);
-        if (tile < ntiles) load_tile(tile);
-#pragma unroll 1
-        for (int ks = 0; ks < WTY * WTX / 16; ++ks) {
-            const int r = ks >> 1, c0 = 16 * (ks & 1) + 8 * h;
-            const int ga = (32 * Ro + l32) * GST + r * WTX + c0;
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gh + ga));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(gl + ga));
-            bf16x8 bh[5], bl[5];
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const int tap = tap0 + (t < ntap ? t : 0), ki = tap / 3, kj = tap - 3 * ki;   // t >= ntap: unused copy
-                const int e0 = (32 * Ri + l32) * XST + (r + ki) * XCOLS + 8 + c0;
-                const uint4 ch = *reinterpret_cast<const uint4 *>(xh + e0);
-                const uint4 cl = *reinterpret_cast<const uint4 *>(xl + e0);
-                bh[t] = __builtin_bit_cast(bf16x8, shifted(xh, e0, ch, kj));
-                bl[t] = __builtin_bit_cast(bf16x8, shifted(xl, e0, cl, kj));
-            }
-            // term-major: consecutive MFMAs go to different accumulators
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-                if (t < ntap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+        if (tile < ntiles && !(dbg & 1)) load_tile(tile);
+        if (!(dbg & 2)) {
+            if (wv >> 2) wgrad_tile<5, 4>(gh, gl, xh, xl, Ro, Ri, l32, h, acc);
+            else wgrad_tile<0, 5>(gh, gl, xh, xl, Ro, Ri, l32, h, acc);
         }
     }
     // partial[((og * Pd + kd) * nwg + wg) * 9 + tap][o_local 64][i 64]
@@ -620,7 +624,8 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
         attr_done = true;
     }
     k_dense_wgrad<<<dim3((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups), WNT, lds, S(stream)>>>(
-        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles, vec);
+        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles, vec,
+        getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0);
     CDL_LAUNCH_CHECK();
     k_dense_wfold<<<(unsigned)(g->M * g->Pd * 9), 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
     CDL_LAUNCH_CHECK();
