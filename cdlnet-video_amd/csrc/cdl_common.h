@@ -118,7 +118,8 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
                     float *ws, size_t ws_floats, void *stream);
 int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float *in_gate, const float *w,
                    float alpha, const float *add, const float *add_gate, const float *mask, const float *sub,
-                   const float *tau, int relu, float *out, float *ws, size_t ws_floats, void *stream);
+                   const float *tau, int relu, const float *out_gate, float *out, float *ws, size_t ws_floats,
+                   void *stream);
 int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                       const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
                       size_t ws_floats, void *stream);

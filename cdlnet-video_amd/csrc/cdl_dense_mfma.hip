@@ -15,7 +15,8 @@
 // (two co-resident workgroups with unpipelined staging measured 0.22 ms per 64->64 3x3x3 convolution of a
 // 16 x 128 x 128 volume, 31 % of the MFMA rate).
 // Epilogue straight from the accumulators (lanes l32 = 32 consecutive x: 128-byte segments):
-//     v = alpha * acc;  v *= mask;  v += add [where add_gate != 0];  v -= sub;  v = ST(v, tau);  v = max(v, 0)
+//     v = alpha * acc;  v *= mask;  v += add [where add_gate != 0];  v -= sub;  v = ST(v, tau);  v = max(v, 0);
+//     v = 0 where out_gate == 0
 // which covers the analysis role (add = zin, tau), the synthesis role (transposed + flipped weights, input gate,
 // mask, sub) and the ResidualBlock's fused relu.
 #include "cdl_common.h"
@@ -34,7 +35,7 @@ struct DenseArgs {
     const float *x, *in_gate;
     const uint4 *frags;
     float alpha;
-    const float *add, *add_gate, *mask, *sub, *tau;
+    const float *add, *add_gate, *mask, *sub, *tau, *out_gate;
     int relu;
     float *out;
     int N, I, O, D, H, W, Pd, Ph, Pw, tilesX, tilesY, NCC, MTT;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
     const float *ag_n = (a.add && a.add_gate) ? a.add_gate + nbase : nullptr;
     const float *mask_n = a.mask ? a.mask + nbase : nullptr;
     const float *sub_n = a.sub ? a.sub + nbase : nullptr;
+    const float *og_n = a.out_gate ? a.out_gate + nbase : nullptr;
     float *out_n = a.out + nbase;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
                 if (sub_n) val -= sub_n[idx];
                 if (a.tau) val = cdl_shrink(val, a.tau[n * a.O + m]);
                 if (a.relu) val = fmaxf(val, 0.0f);
+                if (og_n && og_n[idx] == 0.0f) val = 0.0f;
                 out_n[idx] = val;
             }
         }
@@ -280,7 +283,8 @@ size_t cdl_dense_ws_floats(const cdl_geom *g, int transpose)
 // CDL_EUNSUPPORTED: the caller falls back to the other tiers.
 int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float *in_gate, const float *w,
                    float alpha, const float *add, const float *add_gate, const float *mask, const float *sub,
-                   const float *tau, int relu, float *out, float *ws, size_t ws_floats, void *stream)
+                   const float *tau, int relu, const float *out_gate, float *out, float *ws, size_t ws_floats,
+                   void *stream)
 {
     DensePlan p;
     const int in = transpose ? g->M : g->C, outc = transpose ? g->C : g->M;
@@ -291,7 +295,7 @@ int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float
     k_dense_prep<<<(nprep + 255) / 256, 256, 0, S(stream)>>>(w, frags, outc, in, g->Pd, g->Ph, g->Pw, p.MTT, p.NCC,
                                                               transpose);
     CDL_LAUNCH_CHECK();
-    const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, relu, out,
+    const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, out_gate, relu, out,
                       g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT,
                       getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0};
     return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));

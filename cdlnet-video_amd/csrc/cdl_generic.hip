@@ -632,7 +632,7 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
     if (gate && !zin) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
         if (!px.zp && mfma_dense_enabled()) {
-            const int rcd = cdl_dense_conv(g, 0, x, nullptr, w, alpha, zin, gate, nullptr, nullptr, tau, 0, out, ws,
+            const int rcd = cdl_dense_conv(g, 0, x, nullptr, w, alpha, zin, gate, nullptr, nullptr, tau, 0, nullptr, out, ws,
                                            ws_floats, stream);
             if (rcd != CDL_EUNSUPPORTED) return rcd;
         }
@@ -690,7 +690,7 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
     if (!getenv("CDL_NO_TILED")) {
         if (mfma_dense_enabled()) {
-            const int rcd = cdl_dense_conv(g, 1, z, gate, w, alpha, nullptr, nullptr, mask, sub, nullptr, 0, out,
+            const int rcd = cdl_dense_conv(g, 1, z, gate, w, alpha, nullptr, nullptr, mask, sub, nullptr, 0, nullptr, out,
                                            workspace, workspace_floats, stream);
             if (rcd != CDL_EUNSUPPORTED) return rcd;
         }

@@ -36,6 +36,14 @@ __global__ __launch_bounds__(256) void k_relu(float *__restrict__ v, size_t n4, 
     if (i < n - 4 * n4) v[4 * n4 + i] = fmaxf(v[4 * n4 + i], 0.0f);
 }
 
+// dst = g where gate != 0, else 0
+__global__ __launch_bounds__(256) void k_gate(float *__restrict__ dst, const float *__restrict__ gsrc,
+                                              const float *__restrict__ gate, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = gate[i] != 0.0f ? gsrc[i] : 0.0f;
+}
+
 // acc += g where gate != 0
 __global__ __launch_bounds__(256) void k_add_gated(float *__restrict__ acc, const float *__restrict__ gsrc,
                                                    const float *__restrict__ gate, size_t n)
@@ -80,10 +88,10 @@ int cdl_residual_forward(const cdl_geom *g, const float *x, const float *w1, con
     // dense matrix-core tier: the relu is the convolution's epilogue (2 launches + 2 fragment preps per block)
     const char *e = getenv("CDL_MFMA_DENSE");
     if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED")) {
-        const int rc = cdl_dense_conv(g, 0, x, nullptr, w1, 1.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 1, h,
+        const int rc = cdl_dense_conv(g, 0, x, nullptr, w1, 1.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, h,
                                       scratch, scratch_floats, stream);
         if (rc == 0)
-            return cdl_dense_conv(g, 0, h, nullptr, w2, 1.0f, x, nullptr, nullptr, nullptr, nullptr, 1, out, scratch,
+            return cdl_dense_conv(g, 0, h, nullptr, w2, 1.0f, x, nullptr, nullptr, nullptr, nullptr, 1, nullptr, out, scratch,
                                   scratch_floats, stream);
         if (rc != CDL_EUNSUPPORTED) return rc;
     }
@@ -101,17 +109,26 @@ int cdl_residual_backward(const cdl_geom *g, const float *x, const float *h, con
         return CDL_EINVAL;
     if (scratch_floats < cdl_residual_scratch_floats(g) || (scratch_floats && !scratch)) return CDL_EINVAL;
     const size_t n = (size_t)g->N * g->M * g->D * g->H * g->W;
+    {   // dense tier: each relu gate is applied ONCE, where the gated gradient is produced (g2 by one element-wise
+        // pass into dx, which is free until the last launch; g1 by the epilogue of the launch that computes dh), so
+        // the two data-gradient and two filter-gradient launches read no gate (each re-reads its input ~3x)
+        const char *e = getenv("CDL_MFMA_DENSE");
+        if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED") && cdl_dense_ws_floats(g, 1) && cdl_dense_wgrad_ws_floats(g)) {
+            float *g2 = dx;
+            k_gate<<<(unsigned)((n + 255) / 256), 256, 0, S(stream)>>>(g2, g_out, out, n);
+            CDL_LAUNCH_CHECK();
+            CDL_TRY(cdl_dense_conv(g, 1, g2, nullptr, w2, 1.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h, dh,
+                                   scratch, scratch_floats, stream));                     // dh = S(g2; w2) [h > 0] = g1
+            CDL_TRY(cdl_wgrad(g, g2, nullptr, h, 1.0f, dw2, scratch, scratch_floats, stream));
+            CDL_TRY(cdl_wgrad(g, dh, nullptr, x, 1.0f, dw1, scratch, scratch_floats, stream));
+            // dx = S(g1; w1) + g2, g2 read from dx itself: every element is read and then written by the same thread
+            return cdl_dense_conv(g, 1, dh, nullptr, w1, 1.0f, g2, nullptr, nullptr, nullptr, nullptr, 0, nullptr, dx,
+                                  scratch, scratch_floats, stream);
+        }
+    }
     CDL_TRY(cdl_synthesis_ws(g, g_out, out, w2, 1.0f, nullptr, nullptr, dh, scratch, scratch_floats, stream));
     CDL_TRY(cdl_wgrad(g, g_out, out, h, 1.0f, dw2, scratch, scratch_floats, stream));
     CDL_TRY(cdl_wgrad(g, dh, h, x, 1.0f, dw1, scratch, scratch_floats, stream));
-    {   // dense tier: the skip connection's g2 is added in the data-gradient launch's epilogue
-        const char *e = getenv("CDL_MFMA_DENSE");
-        if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED")) {
-            const int rc = cdl_dense_conv(g, 1, dh, h, w1, 1.0f, g_out, out, nullptr, nullptr, nullptr, 0, dx, scratch,
-                                          scratch_floats, stream);
-            if (rc != CDL_EUNSUPPORTED) return rc;
-        }
-    }
     CDL_TRY(cdl_synthesis_ws(g, dh, h, w1, 1.0f, nullptr, nullptr, dx, scratch, scratch_floats, stream));
     k_add_gated<<<(unsigned)((n + 255) / 256), 256, 0, S(stream)>>>(dx, g_out, out, n);
     CDL_LAUNCH_CHECK();
