@@ -398,10 +398,11 @@ __device__ __forceinline__ void wgrad_tile(const __bf16 *gh, const __bf16 *gl, c
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G, const float *__restrict__ gate,
                                                      const float *__restrict__ X, float *__restrict__ partial,
                                                      int N, int O, int I, int D, int H, int W, int Pd, int tilesX,
-                                                     int tilesY, int ntiles, int vec, int dbg)
+                                                     int tilesY, int ntiles, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *gh = reinterpret_cast<__bf16 *>(smem);         // [64][GST]
@@ -421,10 +422,29 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
 
     // The next tile's global loads are issued into registers before the current tile's MFMAs and parked in LDS
     // after them (one batch of loads in flight per tile instead of a chain of dependent round trips).
-    constexpr int NG = 64 * WTY * 4 / WNT, NX = (64 * (WTY + 2) * 6 + WNT - 1) / WNT;     // 2 and 5 items per thread
-    float pg[NG][8], pgg[NG][8], px[NX][8];
+    // items per thread: 2 G chunks (8 pixels of one channel), 3 X chunks, 2 X halo elements.  Every load is
+    // unconditional at a clamped address and zeroed by a select afterwards: divergent branches around the loads ended
+    // in vmcnt(0) joins, which serialised them and kept them from running under the previous tile's MFMAs.
+    constexpr int NG = 64 * WTY * 4 / WNT, NX = 64 * (WTY + 2) * 4 / WNT, NH = (64 * (WTY + 2) * 2 + WNT - 1) / WNT;
+    float pg[NG][8], pgg[NG][8], px[NX][8], phal[NH];
     auto tile_valid = [&](int t) { const int d = (t / (tilesX * tilesY)) % D; return d + kd - pd >= 0 && d + kd - pd < D; };
     auto next_tile = [&](int t) { while (t < ntiles && !tile_valid(t)) t += gridDim.x; return t; };
+    auto load8 = [&](const float *base, int off, int x0, bool rowok, float (&v)[8]) {
+        if constexpr (VEC) {                               // W % 4 == 0, aligned bases, x0 % 8 == 0
+            const bool ok2 = rowok && x0 + 4 <= W, ok = rowok && x0 + 8 <= W;
+            const float4 a = *reinterpret_cast<const float4 *>(base + (ok2 ? off : 0));
+            const float4 c = *reinterpret_cast<const float4 *>(base + (ok ? off + 4 : 0));
+            v[0] = ok2 ? a.x : 0.0f; v[1] = ok2 ? a.y : 0.0f; v[2] = ok2 ? a.z : 0.0f; v[3] = ok2 ? a.w : 0.0f;
+            v[4] = ok ? c.x : 0.0f; v[5] = ok ? c.y : 0.0f; v[6] = ok ? c.z : 0.0f; v[7] = ok ? c.w : 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = rowok && x0 + e < W;
+                const float t = base[ok ? off + e : 0];
+                v[e] = ok ? t : 0.0f;
+            }
+        }
+    };
     auto load_tile = [&](int tile) {
         int b = tile;
         const int tx = b % tilesX; b /= tilesX;
@@ -443,52 +463,29 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
             const int y = ty * WTY + row, x0 = tx * WTX + cg * 8, oo = o0 + o;
             const bool rowok = oo < O && y < H;
             const int off = rowok ? oo * cstride + y * W + x0 : 0;
-            if (vec) {                                     // 16-byte loads: W % 4 == 0, aligned bases, x0 % 8 == 0
-                const bool ok = rowok && x0 + 8 <= W;      // W % 4 == 0 and x0 % 8 == 0: a chunk is all in or all out ...
-                const bool ok2 = rowok && x0 + 4 <= W;     // ... except its first half at the right edge
-                const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f}, one4 = {1.0f, 1.0f, 1.0f, 1.0f};
-                const float4 a = ok2 ? *reinterpret_cast<const float4 *>(Gt + off) : z4;
-                const float4 c = ok ? *reinterpret_cast<const float4 *>(Gt + off + 4) : z4;
-                const float4 ga = (ok2 && Tt) ? *reinterpret_cast<const float4 *>(Tt + off) : one4;
-                const float4 gc = (ok && Tt) ? *reinterpret_cast<const float4 *>(Tt + off + 4) : one4;
-                pg[j][0] = a.x; pg[j][1] = a.y; pg[j][2] = a.z; pg[j][3] = a.w;
-                pg[j][4] = c.x; pg[j][5] = c.y; pg[j][6] = c.z; pg[j][7] = c.w;
-                pgg[j][0] = ga.x; pgg[j][1] = ga.y; pgg[j][2] = ga.z; pgg[j][3] = ga.w;
-                pgg[j][4] = gc.x; pgg[j][5] = gc.y; pgg[j][6] = gc.z; pgg[j][7] = gc.w;
-            } else {
+            load8(Gt, off, x0, rowok, pg[j]);
+            if (Tt) load8(Tt, off, x0, rowok, pgg[j]);     // uniform
+            else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = rowok && x0 + e < W;
-                    pg[j][e] = ok ? Gt[off + e] : 0.0f;
-                    pgg[j][e] = (ok && Tt) ? Tt[off + e] : 1.0f;
-                }
+                for (int e = 0; e < 8; ++e) pgg[j][e] = 1.0f;
             }
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int it = threadIdx.x + j * WNT;
-            const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
-            const int y = ty * WTY - 1 + row, x0 = tx * WTX - 8 + cg * 8;
-            const bool rowok = i < I && y >= 0 && y < H;       // i >= 64 (items past the end) fail i < I <= 64
-            const int off = rowok ? i * cstride + y * W : 0;
-            const bool halo = cg == 0 || cg == 5;              // only the element next to the tile is read
-            if (vec) {
-                const bool ok2 = rowok && !halo && x0 + 4 <= W, ok = rowok && !halo && x0 + 8 <= W;
-                const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float4 a = ok2 ? *reinterpret_cast<const float4 *>(Xt + off + x0) : z4;
-                const float4 c = ok ? *reinterpret_cast<const float4 *>(Xt + off + x0 + 4) : z4;
-                const int xe = cg == 0 ? x0 + 7 : x0;
-                const float edge = (rowok && halo && xe >= 0 && xe < W) ? Xt[off + xe] : 0.0f;
-                px[j][0] = cg == 5 ? edge : a.x; px[j][1] = a.y; px[j][2] = a.z; px[j][3] = a.w;
-                px[j][4] = c.x; px[j][5] = c.y; px[j][6] = c.z; px[j][7] = cg == 0 ? edge : c.w;
-            } else {
+            const int cg = it & 3, row = (it >> 2) % (WTY + 2), i = it / (4 * (WTY + 2));
+            const int y = ty * WTY - 1 + row, x0 = tx * WTX + cg * 8;
+            const bool rowok = i < I && y >= 0 && y < H;
+            load8(Xt, rowok ? i * cstride + y * W + x0 : 0, x0, rowok, px[j]);
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int xx = x0 + e;
-                    const bool need = !halo || (cg == 0 ? e == 7 : e == 0);
-                    px[j][e] = (rowok && need && xx >= 0 && xx < W) ? Xt[off + xx] : 0.0f;
-                }
-            }
+        for (int j = 0; j < NH; ++j) {                     // the one element either side of every tile row
+            const int it = threadIdx.x + j * WNT;
+            const int side = it & 1, row = (it >> 1) % (WTY + 2), i = it / (2 * (WTY + 2));
+            const int y = ty * WTY - 1 + row, xe = side ? tx * WTX + WTX : tx * WTX - 1;
+            const bool ok = i < I && y >= 0 && y < H && xe >= 0 && xe < W;      // i >= 64 (items past the end): i < I fails
+            const float t = Xt[ok ? i * cstride + y * W + xe : 0];
+            phal[j] = ok ? t : 0.0f;
         }
     };
     auto store_tile = [&]() {
@@ -507,12 +504,21 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int it = threadIdx.x + j * WNT;
-            if (it < 64 * (WTY + 2) * 6) {
-                const int cg = it % 6, row = (it / 6) % (WTY + 2), i = it / (6 * (WTY + 2));
-                uint4 hi, lo;
-                split8(px[j], hi, lo);
-                *reinterpret_cast<uint4 *>(xh + i * XST + row * XCOLS + cg * 8) = hi;
-                *reinterpret_cast<uint4 *>(xl + i * XST + row * XCOLS + cg * 8) = lo;
+            const int cg = it & 3, row = (it >> 2) % (WTY + 2), i = it / (4 * (WTY + 2));
+            uint4 hi, lo;
+            split8(px[j], hi, lo);
+            *reinterpret_cast<uint4 *>(xh + i * XST + row * XCOLS + 8 + cg * 8) = hi;
+            *reinterpret_cast<uint4 *>(xl + i * XST + row * XCOLS + 8 + cg * 8) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const int it = threadIdx.x + j * WNT;
+            if (it < 64 * (WTY + 2) * 2) {
+                const int side = it & 1, row = (it >> 1) % (WTY + 2), i = it / (2 * (WTY + 2));
+                const __bf16 hh = (__bf16)phal[j];
+                const int slot = i * XST + row * XCOLS + (side ? 8 + WTX : 7);   // the other 7 halo slots are never used:
+                xh[slot] = hh;                                                    // the funnel shift keeps one element
+                xl[slot] = (__bf16)(phal[j] - (float)hh);
             }
         }
     };
@@ -528,6 +534,8 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
         for (int j = 0; j < NX; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e) px[j][e] = 1.0f;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) phal[j] = 1.0f;
     }
 #pragma unroll 1
     while (tile < ntiles) {
@@ -617,19 +625,27 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
     WgradPlan p;
     if (!wgrad_plan(g, &p)) return CDL_EUNSUPPORTED;
     if (!ws || ws_floats < p.ws) return CDL_EUNSUPPORTED;
-    static bool attr_done = false;
     const int vec = (g->W % 4 == 0) && !((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(x) |
                                            reinterpret_cast<size_t>(gate)) & 15);
     const size_t lds = (size_t)(64 * GST + 64 * XST) * 2 * sizeof(__bf16);
+    static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_dense_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_dense_wgrad<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_dense_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    k_dense_wgrad<<<dim3((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups), WNT, lds, S(stream)>>>(
-        F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd, p.tilesX, p.tilesY, p.ntiles, vec,
-        getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0);
+    const int dbg = getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0;
+    const dim3 grid((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups);
+    if (vec)
+        k_dense_wgrad<true><<<grid, WNT, lds, S(stream)>>>(F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd,
+                                                           p.tilesX, p.tilesY, p.ntiles, dbg);
+    else
+        k_dense_wgrad<false><<<grid, WNT, lds, S(stream)>>>(F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd,
+                                                            p.tilesX, p.tilesY, p.ntiles, dbg);
     CDL_LAUNCH_CHECK();
     k_dense_wfold<<<(unsigned)(g->M * g->Pd * 9), 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
     CDL_LAUNCH_CHECK();
