@@ -83,7 +83,11 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
     uint4 *xl = xh + (size_t)npix * 2;                     // lo parts
     uint4 *wl = xl + (size_t)npix * 2;                     // [taps][MT][2][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    int b = blockIdx.x;
+    // workgroup -> tile: workgroups are dealt to the 8 XCDs round robin, so workgroup b gets the (b / 8)-th tile of
+    // XCD (b % 8)'s contiguous eighth of the tile list: tiles that share halo rows and kd planes share an L2
+    // (round-robin tiles read 424 MB from HBM per launch against 67 MB of input, profiles/r01_dense_pmc.json)
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, fl = nb >> 3, rem = nb & 7;
+    int b = xcd * fl + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int tx = b % a.tilesX; b /= a.tilesX;
     const int ty = b % a.tilesY; b /= a.tilesY;
     const int zd = b % a.D, n = b / a.D;
@@ -428,6 +432,9 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
     constexpr int NG = 64 * WTY * 4 / WNT, NX = 64 * (WTY + 2) * 4 / WNT, NH = (64 * (WTY + 2) * 2 + WNT - 1) / WNT;
     float pg[NG][8], pgg[NG][8], px[NX][8], phal[NH];
     auto tile_valid = [&](int t) { const int d = (t / (tilesX * tilesY)) % D; return d + kd - pd >= 0 && d + kd - pd < D; };
+    // a workgroup walks tiles blockIdx.x, +gridDim.x, ...; gridDim.x is a multiple of 8, so the Pd workgroups that
+    // need the same G tile at about the same time (same blockIdx.x, different kd) sit on one XCD and share its L2
+    // (contiguous tile ranges per workgroup read MORE from HBM: 928 MB against 792 MB per launch)
     auto next_tile = [&](int t) { while (t < ntiles && !tile_valid(t)) t += gridDim.x; return t; };
     auto load8 = [&](const float *base, int off, int x0, bool rowok, float (&v)[8]) {
         if constexpr (VEC) {                               // W % 4 == 0, aligned bases, x0 % 8 == 0
@@ -604,6 +611,7 @@ bool wgrad_plan(const cdl_geom *g, WgradPlan *p)
     p->ogroups = (g->M + 63) / 64;
     if (p->ogroups > 65535 || g->Pd > 65535) return false;
     p->nwg = WG_TOTAL / (g->Pd * p->ogroups);
+    if (p->nwg >= 8) p->nwg &= ~7;                        // multiple of 8: XCD = blockIdx.x % 8 for every (kd, group)
     if (p->nwg < 1) p->nwg = 1;
     if (p->nwg > p->ntiles) p->nwg = p->ntiles;
     p->ws = (size_t)p->ogroups * g->Pd * p->nwg * 9 * 4096;

@@ -1,4 +1,6 @@
-"""Timing probes of the dense convolution kernel (CDL_DENSE_DEBUG: results are NOT valid, timing only)."""
+"""Timing probes of the dense convolution kernels (CDL_DENSE_DEBUG bits: 1 no global loads, 2 no MFMAs, 4 no
+epilogue / LDS stores; results are NOT valid when set, timing only).  `dense_probe.py 0` = the real kernels only
+(used under rocprofv3 --pmc)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -17,7 +19,7 @@ def ev(fn, reps=20):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-for dbg in ("0", "1", "2", "3", "4", "6", "7"):
+for dbg in (sys.argv[1:] or ("0", "1", "2", "3", "4", "6", "7")):
     os.environ["CDL_DENSE_DEBUG"] = dbg
     print("dbg", dbg, "analysis ms", round(ev(lambda: o.analysis(g, x, w1, out=out)), 4),
           "wgrad ms", round(ev(lambda: o.wgrad(g, out, x, 1.0, gate=x)), 4), flush=True)
