@@ -414,8 +414,13 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
     __bf16 *xh = gl + 64 * GST;                            // [64][XST]
     __bf16 *xl = xh + 64 * XST;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const int Ro = (wv >> 1) & 1, Ri = wv & 1, tap0 = (wv >> 2) ? 5 : 0, ntap = (wv >> 2) ? 4 : 5;
     const int kd = blockIdx.y, o0 = 64 * blockIdx.z, pd = Pd / 2;
+    // <= 32 channels on both sides: one 32 x 32 channel pair, the 9 taps dealt over the 8 waves (wave 7 takes two) --
+    // the 2 x 2 pair layout would spend three quarters of its MFMAs on zero padding
+    const bool narrow = I <= 32 && O - o0 <= 32;
+    const int Ro = narrow ? 0 : (wv >> 1) & 1, Ri = narrow ? 0 : wv & 1;
+    const int tap0 = narrow ? (wv < 7 ? wv : 7) : ((wv >> 2) ? 5 : 0);
+    const int ntap = narrow ? (wv < 7 ? 1 : 2) : ((wv >> 2) ? 4 : 5);
     const size_t plane = (size_t)H * W;
 
     f32x16 acc[5];
@@ -552,7 +557,18 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
         tile = next_tile(tile + gridDim.x);
         if (tile < ntiles && !(dbg & 1)) load_tile(tile);
         if (!(dbg & 2)) {
-            if (wv >> 2) wgrad_tile<5, 4>(gh, gl, xh, xl, Ro, Ri, l32, h, acc);
+            if (narrow) {
+                switch (wv) {                              // wave-uniform
+                case 0: wgrad_tile<0, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 1: wgrad_tile<1, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 2: wgrad_tile<2, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 3: wgrad_tile<3, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 4: wgrad_tile<4, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 5: wgrad_tile<5, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                case 6: wgrad_tile<6, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                default: wgrad_tile<7, 2>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
+                }
+            } else if (wv >> 2) wgrad_tile<5, 4>(gh, gl, xh, xl, Ro, Ri, l32, h, acc);
             else wgrad_tile<0, 5>(gh, gl, xh, xl, Ro, Ri, l32, h, acc);
         }
     }
