@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--precision", default="split3", choices=["split3", "bf16"],
                     help="fused-kernel arithmetic: split-bf16 x3 (fp32-grade, default) or plain bf16")
     ap.add_argument("--backend", default="auto", choices=["auto", "generic"])
+    ap.add_argument("--code-storage", default="fp32", choices=["fp32", "bf16", "fp32-nchw"],
+                    help="how the fused sweeps store the codes that never leave them: fp32 pixel-blocked (default, "
+                         "bit-identical to the reference layout), bf16 pixel-blocked (opt-in: half the fat bytes, "
+                         "PSNR parity only), or fp32 in the reference's NCHW layout")
     return ap.parse_args()
 
 
@@ -100,22 +104,26 @@ def kernel_probe(cva, net, batch, size, reps=5):
     fat = z.numel() * 4
     th = x.numel() * 4
     if loop.BACKEND == "auto" and o.fused_supported(g):
-        prec = loop.PRECISION
+        prec, lay = loop.PRECISION, loop.CODE_LAYOUT
         frags = o.fused_prep(w, w)
         patches = o.fused_patches(g, dev)
         ws = o.fused_wgrad_workspace(g, dev)
         dtp = torch.empty((o.fused_tiles(g), M), device=dev)
         bits = o.fused_support_map(g, z)             # what the training forward writes next to z' (2 bits/element)
         mapb = bits.numel() * 4
+        # operands in the layout the sweeps keep them in (the codes of a sweep never leave it)
+        zl, gl = o.fused_from_nchw(g, z, lay), o.fused_from_nchw(g, gup, lay)
+        outl = o.fused_code_buffer(g, lay, dev)[0]
+        fat = outl.numel() * outl.element_size()
         table = {
             f"k_stage<FWD,{prec}> (z'=ST(z-A r), patches of B z', support map)":
-                (lambda: o.fused_iter(g, x, z, tau, frags, -1.0, patches, prec, out=out, map_out=bits), K,
-                 2 * fat + mapb + 2 * th),
+                (lambda: o.fused_iter(g, x, zl, tau, frags, -1.0, patches, prec, out=outl, map_out=bits,
+                                      lay_in=lay, lay_out=lay), K, 2 * fat + mapb + 2 * th),
             f"k_stage<BWD,{prec}> (du=[z'!=0](du'+B^T q), dtau, patches of A^T du)":
-                (lambda: o.fused_stage_bwd(g, x, gup, bits, frags, patches, dtp, True, prec, out=out), K,
-                 2 * fat + mapb + 2 * th),
+                (lambda: o.fused_stage_bwd(g, x, gl, bits, frags, patches, dtp, True, prec, out=outl,
+                                           lay_in=lay, lay_out=lay), K, 2 * fat + mapb + 2 * th),
             f"k_wgrad2d<{prec}> (dA_k and dB_k)":
-                (lambda: o.fused_wgrad(g, ws, gup, x, -1.0, z, x, 1.0, prec), K, 2 * fat + 2 * th),
+                (lambda: o.fused_wgrad(g, ws, gl, x, -1.0, zl, x, 1.0, prec, layout=lay), K, 2 * fat + 2 * th),
             "k_assemble (thin)": (lambda: o.fused_assemble(g, patches, None, x, 1.0, out=thin), 2 * K, 3 * th),
             "k_prep (weights -> bf16 fragments)": (lambda: o.fused_prep(w, w), 2 * K, 0),
         }
@@ -138,12 +146,21 @@ def kernel_probe(cva, net, batch, size, reps=5):
     return rows, dom
 
 
-def pmc_traffic(kernel_label, batch, size, M, P):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile
-    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
-    doubled per the gfx950 correction and calibrated on a plain copy).  None when no profile matches
-    this shape (counters cannot be read from inside the timed process)."""
+def kernel_source_sha():
+    """Identifies the kernel revision a PMC profile was taken from."""
+    import hashlib
+    src = os.path.join(ROOT, "cdlnet-video_amd", "csrc", "cdl_fused2d.hip")
+    return hashlib.sha1(open(src, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel_label, batch, size, M, P, layout):
+    """HBM bytes per launch of the dominant kernel from a committed PMC profile of THIS kernel revision
+    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_kernels.py,
+    FETCH_SIZE doubled per the gfx950 correction; the file records the sha1 of cdl_fused2d.hip and the code
+    layout it was taken with).  None when no profile matches shape, layout and source: counters cannot be read
+    from inside the timed process, and a profile of an older revision says nothing about this one."""
     import glob
+    sha = kernel_source_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             prof = json.load(open(path))
@@ -151,6 +168,8 @@ def pmc_traffic(kernel_label, batch, size, M, P):
             continue
         sh = prof.get("shape", {})
         if (sh.get("N"), sh.get("M"), sh.get("H"), sh.get("W"), sh.get("P")) != (batch, M, size, size, P):
+            continue
+        if prof.get("kernel_source_sha") != sha or prof.get("layout") != layout:
             continue
         for name, row in prof.get("kernels", {}).items():
             if kernel_label.startswith(name):           # e.g. "k_stage<BWD,split3>" prefixes the probe label
@@ -199,6 +218,7 @@ def main():
     from cdlnet_video_amd import loop
     loop.set_backend(args.backend)
     loop.set_precision(args.precision)
+    loop.set_code_layout({"fp32": "blocked", "bf16": "blocked_bf16", "fp32-nchw": "nchw"}[args.code_storage])
     K, M, P, B, S = args.K, args.M, args.P, args.batch, args.size
     torch.manual_seed(1)
     # the constructor prints its power-method log like the reference's; stdout carries the JSON line only
@@ -284,14 +304,16 @@ def main():
             dom = max(rows, key=lambda k: rows[k]["share_ms"])
         d = rows[dom]
         note("kernel probe done")
-        traffic, traffic_src = pmc_traffic(dom, B, S, M, P)
+        traffic, traffic_src = pmc_traffic(dom, B, S, M, P, loop.CODE_LAYOUT)
         out = {
             "metric": f"Mpix/s denoised (fwd+bwd) at K={K},M={M},P={P}",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (split-bf16 x3 MFMA, fp32 accumulate, fp32 storage)" if args.precision == "split3"
-            else "bf16 MFMA, fp32 accumulate, fp32 storage", "data": "synthetic",
+            "dtype": ("f32 (split-bf16 x3 MFMA, fp32 accumulate" if args.precision == "split3"
+                      else "bf16 MFMA (fp32 accumulate") +
+                     (", bf16 code STORAGE: opt-in, PSNR parity only)" if args.code_storage == "bf16" else ", fp32 storage)"),
+            "data": "synthetic", "code_layout": loop.CODE_LAYOUT,
             "config": {"workload": f"CDLNet K={K} M={M} P={P} s=1 C=1 train step (fwd+bwd+Adam+project), "
                                    f"batch {B}x1x{S}x{S} per GPU, sigma=25",
                        "global_batch": world * B, "parallelism": f"dp{world}"},

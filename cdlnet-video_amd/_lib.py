@@ -62,6 +62,7 @@ SIGNATURES = {
     "cdl_project_filter_banks": [_P, _I, _I, _I, _P],
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cdl_options_reload": [],
     "cdl_fused2d_supported": [_G],
     "cdl_fused2d_prep": [_P, _P, _P, _I, _I, _P],
     "cdl_fused2d_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
@@ -74,8 +75,17 @@ SIGNATURES = {
     "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
     "cdl_fused2d_forward": [_G, _I] + [_P] * 11 + [_I, _P],
     "cdl_fused2d_backward": [_G, _I] + [_P] * 20 + [_I, _P],
+    "cdl_fusedg_supported": [_G],
+    "cdl_fusedg_prep": [_G, _P, _P, _P, _P],
+    "cdl_fusedg_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
+    "cdl_fusedg_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "cdl_fusedg_assemble": [_G, _P, _P, _P, _F, _P, _P],
+    "cdl_fusedg_dtau_reduce": [_G, _P, _P, _P, _P, _P],
+    "cdl_fusedg_forward": [_G, _I] + [_P] * 11 + [_I, _P],
+    "cdl_fusedg_backward": [_G, _I] + [_P] * 20 + [ctypes.c_size_t, _I, _P],
 }
-SIZE_T_FUNCS = {"cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G],
+SIZE_T_FUNCS = {"cdl_fusedg_frag_bytes": [_G], "cdl_fusedg_patch_floats": [_G], "cdl_fusedg_tiles": [_G],
+                "cdl_fusedg_map_words": [_G], "cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G], "cdl_fused2d_code_bytes": [_G, _I],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
                 "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G], "cdl_analysis_workspace_floats": [_G],
@@ -104,6 +114,11 @@ def lib():
         handle.cdl_version.argtypes = []
         _lib = handle
     return _lib
+
+
+def reload_options():
+    """Make the library re-read the CDL_* environment switches (it snapshots them at first use)."""
+    check(lib().cdl_options_reload(), "cdl_options_reload")
 
 
 def available():

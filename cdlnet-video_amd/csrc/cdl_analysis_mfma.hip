@@ -220,13 +220,7 @@ template <int PH, int PW, int SW, int MT, bool PROX>
 int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
                const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_ana_m<PH, PW, SW, MT, PROX>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX>, 96 * 1024)) return rc;
     k_ana_m<PH, PW, SW, MT, PROX><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
         *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS);
     CDL_LAUNCH_CHECK();

@@ -9,12 +9,16 @@
         if (e_ != hipSuccess) return -(int)e_;               \
     } while (0)
 
-// sign(u) * max(|u| - t, 0): exactly the reference's x.sign()*relu(|x|-t) (model/net.py:11-14),
-// including t < 0 (|u|-t > 0 everywhere, sign(0) = 0).
+// sign(u) * relu(|u| - t): exactly the reference's x.sign()*relu(|x|-t) (model/net.py:11-14), including
+// t < 0 (|u|-t > 0 everywhere, sign(0) = 0) and non-finite values: a NaN in u or t comes out as NaN (torch's
+// sign and relu both keep it; fmaxf would turn it into 0 and hide a diverging net from the trainer's nan / inf
+// backtracking, train.py:113-142), +-inf stays +-inf.
 __device__ __forceinline__ float cdl_shrink(float u, float t)
 {
-    float m = fmaxf(fabsf(u) - t, 0.0f);
-    return u > 0.0f ? m : (u < 0.0f ? -m : 0.0f);
+    float m = fabsf(u) - t;
+    m = m > 0.0f ? m : (m != m ? m : 0.0f);                          // relu that keeps NaN
+    const float s = u > 0.0f ? 1.0f : (u < 0.0f ? -1.0f : (u != u ? u : 0.0f));      // sign that keeps NaN
+    return s * m;
 }
 
 // ---- CSR proximal maps (reference model/net.py:229-262), shared by cdl_prox.hip and the analysis
@@ -85,6 +89,19 @@ __host__ __device__ __forceinline__ int cdl_floordiv(int a, int b)
     int q = a / b;
     return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
+
+// ---- process-wide switches and per-device bookkeeping (cdl_options.hip) ---------------------------------
+struct cdl_options {
+    int mfma_analysis, mfma_synthesis, mfma_wgrad, mfma_dense;   // 0: use the fp32 VALU kernels instead (CDL_MFMA_*=0)
+    int no_tiled, no_pipelined_synthesis;                        // CDL_NO_TILED, CDL_NO_PIPELINED_SYNTHESIS
+    int fused_snake;                                             // CDL_FUSED_SNAKE=0: no alternating tile direction
+    int fused_grid;                                              // CDL_FUSED_GRID=n: fewer persistent workgroups (probes)
+    int fused_debug, dense_debug;                                // timing-experiment bit masks (results are wrong)
+};
+const cdl_options &cdl_opts();                                   // snapshot of the environment, read once
+int cdl_current_device();
+int cdl_cu_count();                                              // compute units of the CURRENT device
+int cdl_ensure_dynamic_lds(const void *kernel, int bytes);       // per (device, kernel): raise the dynamic-LDS limit once
 
 static inline bool cdl_geom_ok(const cdl_geom *g)
 {

@@ -301,7 +301,7 @@ int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float
     CDL_LAUNCH_CHECK();
     const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, out_gate, relu, out,
                       g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT,
-                      getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0};
+                      cdl_opts().dense_debug};
     return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));
 }
 
@@ -652,17 +652,9 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
     const int vec = (g->W % 4 == 0) && !((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(x) |
                                            reinterpret_cast<size_t>(gate)) & 15);
     const size_t lds = (size_t)(64 * GST + 64 * XST) * 2 * sizeof(__bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_dense_wgrad<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_dense_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
-    const int dbg = getenv("CDL_DENSE_DEBUG") ? atoi(getenv("CDL_DENSE_DEBUG")) : 0;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_dense_wgrad<true>, (int)lds)) return rc;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_dense_wgrad<false>, (int)lds)) return rc;
+    const int dbg = cdl_opts().dense_debug;
     const dim3 grid((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups);
     if (vec)
         k_dense_wgrad<true><<<grid, WNT, lds, S(stream)>>>(F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd,

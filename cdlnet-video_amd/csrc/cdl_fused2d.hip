@@ -28,7 +28,10 @@
 // workgroup writes its (32+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
 // patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "cdl_common.h"
@@ -176,57 +179,103 @@ __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, int vo
 }
 constexpr int OOB = 0x7fff0000;              // byte offset beyond any descriptor range
 
-// 16-byte fat accesses.  In the MFMA C/D layout a lane owns ONE pixel and 4 consecutive channels per
-// register quad; in memory 4 consecutive PIXELS of one channel are contiguous.  So the 4 lanes of a
-// quad each move 16 B (4 pixels of channel 4h + (lane & 3)) and a 4 x 4 transpose inside the quad
-// (two DPP quad_perm exchange stages, 16 VALU ops) converts between the two: 4x fewer memory
-// instructions.  Needs W % 4 == 0 (template WIDE).  Opt-in: see launch_stage for the measured result.
-// A dwordx4 buffer store must be followed by wait states before its data VGPRs are rewritten: with
-// the two the compiler inserts, lanes 12-15 of every 16-lane row of waves 4-7 stored stale data
-// (found by tests/test_gpu_fused.py::test_wide_and_narrow...); WIDE_STORE_NOPS = 16 is clean.
+// ---- layouts of the fat tensors ------------------------------------------------------------------------
+// LAY_NCHW : the reference's (N, M, H, W) fp32.  A wave instruction of the MFMA C/D layout (lane = pixel,
+//            register = channel) touches two 128-B segments in two channel planes; 32 dword accesses per
+//            32-pixel row block.  What callers see (z_K, user gradients) is always this.
+// LAY_BLK  : pixel-blocked fp32 [n][y][x/32][M/4][32 px][4 ch] for tensors that stay INSIDE a sweep (z_1 ..
+//            z_{K-1}, du_k): the 4 consecutive channels a lane owns per register quad are 16 contiguous
+//            bytes, a wave instruction covers 1 KiB contiguous, a row block 8 KiB contiguous -- 8 dwordx4
+//            accesses, no shuffles.  tools/probes/probe_stream.hip (same box, pure load -> store stream of
+//            the cfg2 code tensor): plane-strided dwords 5.08 TB/s, this 5.65 TB/s.
+// LAY_BLK16: the same blocking with bf16 elements (8 bytes per lane): opt-in reduced-precision STORAGE
+//            (half the fat bytes; the 1e-5 parity gate does not hold in this mode).
+enum { LAY_NCHW = 0, LAY_BLK = 1, LAY_BLK16 = 2 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-#ifndef WIDE_STORE_NOPS
-#define WIDE_STORE_NOPS 16          // wait states after a 16-byte store before its data VGPRs may be rewritten
-#endif
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v)
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+__host__ __device__ inline size_t blk_image_elems(int M, int H, int W) { return (size_t)H * ((W + 31) / 32) * M * 32; }
+template <int LAY> __host__ __device__ inline size_t lay_image_bytes(int M, int H, int W)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+    return LAY == LAY_NCHW ? (size_t)M * H * W * 4 : blk_image_elems(M, H, W) * (LAY == LAY_BLK ? 4 : 2);
 }
-// lane p (= lane & 3) register e  <-  lane e register p.  Pure selects (no control flow): DPP reads
-// must see every lane of the quad active.
-__device__ __forceinline__ void quad_transpose(float (&a)[4], int p)
+
+// Buffer descriptor from a WAVE-UNIFORM pointer.  hipcc cannot prove uniformity of anything derived from
+// threadIdx (a wave index, an operator picked per wave group): it then wraps EVERY buffer access in a
+// readfirstlane "waterfall" loop, which serialises the accesses (seen in k_wgrad2d: each of the 8-32 loads of
+// a row block had its own loop; with bf16 storage each was followed by s_waitcnt vmcnt(0)).  Reading the
+// pointer words through readfirstlane makes the descriptor provably scalar.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base, size_t bytes)
 {
-    const bool odd = (p & 1) != 0, hi = (p & 2) != 0;
-    const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-    const float r01 = dpp_quad<0xB1>(odd ? a0 : a1);               // partner lane ^ 1
-    const float r23 = dpp_quad<0xB1>(odd ? a2 : a3);
-    const float b0 = odd ? r01 : a0, b1 = odd ? a1 : r01;
-    const float b2 = odd ? r23 : a2, b3 = odd ? a3 : r23;
-    const float r02 = dpp_quad<0x4E>(hi ? b0 : b2);                // partner lane ^ 2
-    const float r13 = dpp_quad<0x4E>(hi ? b1 : b3);
-    a[0] = hi ? r02 : b0;
-    a[1] = hi ? r13 : b1;
-    a[2] = hi ? b2 : r02;
-    a[3] = hi ? b3 : r13;
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void *b = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(b, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
-__device__ __forceinline__ void buf_ld4(float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
+
+// round-to-nearest-even fp32 -> bf16 -> fp32 (what a bf16-stored code tensor holds)
+__device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }
+
+// 16 consecutive-quad accesses of one accumulator tile set: registers 4q..4q+3 of tile R are channels
+// 32R + 8q + 4h + (0..3) = quad 8R + 2q + h of the blocked layout; `voff` carries (y, xb, h, c), the
+// scalar offset the quad pair.
+// LAY_BLK16 loads kept PACKED (two bf16 per register): decoded where the values are consumed, so that the wait for
+// the loads lands there and not right behind their issue (decoding at the load serialised load latency and the
+// GEMM that should cover it: 0.62 against 0.44 ms for the fp32 layout)
+template <int MT>
+__device__ __forceinline__ void blk16_load_raw(u32x2 (&z)[MT][4], __amdgpu_buffer_rsrc_t rs, int voff)
 {
-    // (bit_cast the whole vector: __builtin_bit_cast(float, v[e]) on a vector ELEMENT reads element 0
-    //  for every e with hipcc / ROCm 7.2 and lets the optimiser shrink the load to one dword)
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-    a[0] = f.x; a[1] = f.y; a[2] = f.z; a[3] = f.w;
+#pragma unroll
+    for (int R = 0; R < MT; ++R)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            z[R][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (8 * R + 2 * q) * 32 * 8, CDL_FAT_LD_AUX));
 }
-__device__ __forceinline__ void buf_st4(const float (&a)[4], __amdgpu_buffer_rsrc_t r, int voff, int soff)
+__device__ __forceinline__ float blk16_decode(const u32x2 &u, int e)
 {
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    const f32x4 f = {a[0], a[1], a[2], a[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, soff, 0);
-    if (WIDE_STORE_NOPS) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop %0" ::"n"(WIDE_STORE_NOPS - 1));
-        __builtin_amdgcn_sched_barrier(0);
+    const unsigned w = (e & 2) ? u.y : u.x;
+    return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+template <int LAY, int MT>
+__device__ __forceinline__ void blk_load(float (&z)[MT][16], __amdgpu_buffer_rsrc_t rs, int voff)
+{
+    constexpr int EB = LAY == LAY_BLK ? 16 : 8;
+#pragma unroll
+    for (int R = 0; R < MT; ++R)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int soff = (8 * R + 2 * q) * 32 * EB;
+            if constexpr (LAY == LAY_BLK) {
+                typedef __attribute__((ext_vector_type(4))) float f32x4;
+                const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, CDL_FAT_LD_AUX));
+                z[R][4 * q + 0] = f.x; z[R][4 * q + 1] = f.y; z[R][4 * q + 2] = f.z; z[R][4 * q + 3] = f.w;
+            } else {
+                const u32x2 u = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, CDL_FAT_LD_AUX));
+                z[R][4 * q + 0] = __builtin_bit_cast(float, u.x << 16);
+                z[R][4 * q + 1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+                z[R][4 * q + 2] = __builtin_bit_cast(float, u.y << 16);
+                z[R][4 * q + 3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+            }
+        }
+}
+// (values of a LAY_BLK16 store must already be bf16-representable: the caller rounds, so that the value it goes
+//  on computing with is the stored one)
+template <int LAY>
+__device__ __forceinline__ void blk_store4(float a0, float a1, float a2, float a3, __amdgpu_buffer_rsrc_t rs, int voff, int quad_pair)
+{
+    constexpr int EB = LAY == LAY_BLK ? 16 : 8;
+    const int soff = quad_pair * 32 * EB;
+    if constexpr (LAY == LAY_BLK) {
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        const f32x4 f = {a0, a1, a2, a3};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), rs, voff, soff, CDL_FAT_ST_AUX);
+    } else {
+        u32x2 u;
+        u.x = (__builtin_bit_cast(unsigned, a0) >> 16) | (__builtin_bit_cast(unsigned, a1) & 0xffff0000u);
+        u.y = (__builtin_bit_cast(unsigned, a2) >> 16) | (__builtin_bit_cast(unsigned, a3) & 0xffff0000u);
+        __builtin_amdgcn_raw_buffer_store_b64(u, rs, voff, soff, CDL_FAT_ST_AUX);
     }
 }
 
@@ -301,7 +350,8 @@ __device__ __forceinline__ float col2im_row(const float (&rv)[4], int h)
 // MODE_FWD / MODE_FIRST: zout = ST(zin + sgn * A r, tau)              (net.py:85,87)
 // MODE_BWD            : zout = [z_{k+1} != 0] * (zin + A-like r),  dtau partials   (reverse sweep);
 //                       support and sign of z_{k+1} come from the 2-bit map, not from the fat tensor
-template <int MT, int PREC, int MODE, bool WIDE>
+//   LIN / LOUT: layouts of zin and zout (LAY_*)
+template <int MT, int PREC, int MODE, int LIN, int LOUT>
 __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -384,7 +434,6 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     const int xl = wxi * 32 + c;             // tile-local pixel column of this lane
     float *rsum = rsum_all + ((wxi & 1) + 2 * (wyi & 1)) * SLAB;
     const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
-    const size_t img = (size_t)M * HW;
     const int hw4 = (int)HW * 4;
 
 #pragma unroll 1
@@ -422,14 +471,17 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
     // register v of accumulator tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
     const bool xok = x < p.W;
-    const __amdgpu_buffer_rsrc_t rs_in = fat_rsrc(has_base ? p.zin + (size_t)n * img : p.zout, has_base ? img : 0);
+    const size_t img_in = lay_image_bytes<LIN>(M, p.H, p.W), img_out = lay_image_bytes<LOUT>(M, p.H, p.W);
+    const __amdgpu_buffer_rsrc_t rs_in = uniform_rsrc(
+        has_base ? (const char *)p.zin + (size_t)n * img_in : (const char *)p.zout, has_base ? img_in : 0);
     // bit 16R + v of the lane's words = register v of tile R: plane 2h holds [z != 0], plane 2h + 1 the sign bit
     unsigned *const map_n = p.map ? p.map + ((size_t)n * 4 + 2 * h) * HW : nullptr;
-    const __amdgpu_buffer_rsrc_t rs_out = fat_rsrc(p.zout + (size_t)n * img, img);
+    const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc((const char *)p.zout + (size_t)n * img_out, img_out);
     const int lane_off = (int)((4 * h) * HW + x) * 4;
-    const int p4 = c & 3;                                  // WIDE: channel 4h + p4, pixels 4(c>>2) .. +3
-    const int xq = tx0 + wxi * 32 + (c & ~3);
-    const int lane_off_w = (int)((4 * h + p4) * HW + xq) * 4;
+    // blocked layouts: block (y, xb) holds M/4 quads of [32 px][4 ch]; the lane's part is (h, c)
+    const int XB = (p.W + 31) / 32, xb = (tx0 >> 5) + wxi;
+    constexpr int EB_IN = LIN == LAY_BLK16 ? 8 : 16, EB_OUT = LOUT == LAY_BLK16 ? 8 : 16;
+    const int lane_blk_in = (h * 32 + c) * EB_IN, lane_blk_out = (h * 32 + c) * EB_OUT;
 
 #pragma unroll 1
     for (int b = 0; b < RB; ++b) {
@@ -437,30 +489,23 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         const int y = ty0 + yl;
         const bool valid = xok && (y < p.H);
         const int voff = valid ? lane_off + y * p.W * 4 : OOB;
-        const int voff_st = (p.dbg & 1) ? OOB : voff;
-        const int voff_w = (xq < p.W && y < p.H) ? lane_off_w + y * p.W * 4 : OOB;
-        const int voff_wst = (p.dbg & 1) ? OOB : voff_w;
+        const int blk = (y * XB + xb) * (M / 4) * 32;            // first [px][4 ch] slot of the block
+        const int voff_in = LIN == LAY_NCHW ? voff : (valid ? blk * EB_IN + lane_blk_in : OOB);
+        const int voff_st = (p.dbg & 1) ? OOB : (LOUT == LAY_NCHW ? voff : (valid ? blk * EB_OUT + lane_blk_out : OOB));
 
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
         float zc[MT][16];
-        if (MODE != MODE_FIRST && (p.dbg & 16)) {
+        u32x2 zr[MT][4];                     // LAY_BLK16: packed, decoded in the epilogue
+        if (MODE != MODE_FIRST && LIN == LAY_BLK16) {
+            blk16_load_raw<MT>(zr, rs_in, voff_in);
+        } else if (MODE != MODE_FIRST && (p.dbg & 16)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) zc[R][v] = 0.25f;
-        } else if (MODE != MODE_FIRST && WIDE && !(p.dbg & 128)) {
-#pragma unroll
-            for (int R = 0; R < MT; ++R)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int soff = (32 * R + 8 * q4) * hw4;
-                    float a[4];
-                    buf_ld4(a, rs_in, voff_w, soff);
-                    quad_transpose(a, p4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) zc[R][4 * q4 + e] = a[e];
-                }
+        } else if (MODE != MODE_FIRST && LIN != LAY_NCHW) {
+            blk_load<LIN, MT>(zc, rs_in, voff_in);
         } else if (MODE != MODE_FIRST) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
@@ -524,29 +569,28 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             for (int v = 0; v < 16; ++v) {
                 const int chl = 32 * R + 8 * (v >> 2) + (v & 3);        // + 4h folded into lane_off
                 float zz;
+                float zbase = 0.0f;
+                if (MODE != MODE_FIRST) zbase = LIN == LAY_BLK16 ? blk16_decode(zr[R][v >> 2], v & 3) : zc[R][v];
                 if (MODE == MODE_BWD) {
                     const bool on = (sup >> (16 * R + v)) & 1u;         // never for out-of-image lanes
-                    zz = on ? zc[R][v] + acc[R][v] : 0.0f;
+                    zz = on ? zbase + acc[R][v] : 0.0f;
                     tsum[16 * R + v] += ((sgb >> (16 * R + v)) & 1u) ? zz : -zz;      // -sign(z') * du
                 } else {
-                    const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
+                    const float base = (MODE == MODE_FWD) ? zbase : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
                     zz = (p.dbg & 64) ? u : (valid ? cdl_shrink(u, taur[16 * R + v]) : 0.0f);
                 }
-                if (!WIDE || (p.dbg & 256)) buf_st(zz, rs_out, voff_st, chl * hw4);
+                if (LOUT == LAY_BLK16) zz = bf16_round(zz);             // the code IS its stored value from here on
+                if (LOUT == LAY_NCHW) buf_st(zz, rs_out, voff_st, chl * hw4);
                 acc[R][v] = zz;
             }
-        if (WIDE && !(p.dbg & 256)) {
+        if (LOUT != LAY_NCHW) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float a[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = acc[R][4 * q4 + e];
-                    quad_transpose(a, p4);
-                    buf_st4(a, rs_out, voff_wst, (32 * R + 8 * q4) * hw4);
-                }
+                for (int q = 0; q < 4; ++q)
+                    blk_store4<LOUT>(acc[R][4 * q], acc[R][4 * q + 1], acc[R][4 * q + 2], acc[R][4 * q + 3], rs_out,
+                                     voff_st, 8 * R + 2 * q);
         }
         if (MODE != MODE_BWD && map_n) {      // training forward: 2 bits per code element for the reverse sweep
             unsigned ws = 0, wg = 0;
@@ -583,7 +627,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     const float val = acc[R][8 * s + jj];
                     const __bf16 hh = (__bf16)val;
                     zh[jj] = hh;
-                    if (PREC == 0) zl[jj] = (__bf16)(val - (float)hh);
+                    if (PREC == 0 && LOUT != LAY_BLK16) zl[jj] = (__bf16)(val - (float)hh);   // a bf16-stored code has no lo part
                 }
 #pragma unroll
                 for (int Rp = 0; Rp < 2; ++Rp) {
@@ -591,7 +635,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     if (PREC == 0) {
                         const bf16x8 wlo = wfrag(OFF_BL + Rp * 2 * MT + 2 * R + s);
                         D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, zh, D[Rp], 0, 0, 0);
-                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl, D[Rp], 0, 0, 0);
+                        if (LOUT != LAY_BLK16) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl, D[Rp], 0, 0, 0);
                     }
                     D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh, D[Rp], 0, 0, 0);
                 }
@@ -768,7 +812,8 @@ struct WgradParams {
     int rev;                 // tiles from last to first
 };
 
-template <int MT, int PREC, bool WIDE>
+//   LAY: layout of the fat operands X[0], X[1] (LAY_*)
+template <int MT, int PREC, int LAY>
 __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -828,23 +873,18 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
             const int yl = wyi * RB + b, y = ty0 + yl;
             const bool valid = xok && y < p.H;
             // ---- fat operand: registers (lanes = pixels) -> bf16 hi/lo -> transposition images
-            const __amdgpu_buffer_rsrc_t rs = fat_rsrc(p.X[op] + (size_t)n * M * HW, (size_t)M * HW);
+            const size_t img_b = lay_image_bytes<LAY>(M, p.H, p.W);
+            const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const char *)p.X[op] + (size_t)n * img_b, img_b);   // op: per wave group
             const int voff = valid ? (int)((4 * h) * HW + (size_t)y * p.W + x) * 4 : OOB;
             const int hw4 = (int)HW * 4;
             float xv[MT][16];
-            if (WIDE) {
-                const int p4 = c & 3, xq = tx0 + wxi * 32 + (c & ~3);
-                const int voff_w = (xq < p.W && y < p.H) ? (int)((4 * h + p4) * HW + (size_t)y * p.W + xq) * 4 : OOB;
-#pragma unroll
-                for (int R = 0; R < MT; ++R)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float a[4];
-                        buf_ld4(a, rs, voff_w, (32 * R + 8 * q4) * hw4);
-                        quad_transpose(a, p4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xv[R][4 * q4 + e] = a[e];
-                    }
+            u32x2 xr[MT][4];                 // LAY_BLK16: the stored bf16 pairs ARE the hi fragments; there is no lo part
+            if (LAY == LAY_BLK16) {
+                const int XB = (p.W + 31) / 32, xb = (tx0 >> 5) + wxi;
+                blk16_load_raw<MT>(xr, rs, valid ? ((y * XB + xb) * (M / 4) * 32 + h * 32 + c) * 8 : OOB);
+            } else if (LAY == LAY_BLK) {
+                const int XB = (p.W + 31) / 32, xb = (tx0 >> 5) + wxi;
+                blk_load<LAY_BLK, MT>(xv, rs, valid ? ((y * XB + xb) * (M / 4) * 32 + h * 32 + c) * 16 : OOB);
             } else {
 #pragma unroll
                 for (int R = 0; R < MT; ++R)
@@ -857,17 +897,21 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 #pragma unroll
                 for (int qv = 0; qv < 4; ++qv) {
                     bf16x4 hi4, lo4;
+                    if (LAY == LAY_BLK16) {
+                        hi4 = __builtin_bit_cast(bf16x4, xr[R][qv]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float val = xv[R][4 * qv + e];
-                        const __bf16 hh = (__bf16)val;
-                        hi4[e] = hh;
-                        lo4[e] = (__bf16)(val - (float)hh);
+                        for (int e = 0; e < 4; ++e) {
+                            const float val = xv[R][4 * qv + e];
+                            const __bf16 hh = (__bf16)val;
+                            hi4[e] = hh;
+                            lo4[e] = (__bf16)(val - (float)hh);
+                        }
                     }
                     const int slot = (2 * qv + h) ^ ((c >> 1) & 7);      // 8-byte slot of channels 8qv+4h..+3
                     __bf16 *dst = wimg + (size_t)(R * 2) * IMG_ELEMS + c * 32 + slot * 4;
                     *reinterpret_cast<bf16x4 *>(dst) = hi4;
-                    if (PREC == 0) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
+                    if (PREC == 0 && LAY != LAY_BLK16) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -903,17 +947,17 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
                         const __bf16 *src = wimg + (size_t)(R * 2) * IMG_ELEMS + row * 32 + slot * 4;
                         part[0][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                             (__attribute__((address_space(3))) bf16x4 *)(src));
-                        if (PREC == 0)
+                        if (PREC == 0 && LAY != LAY_BLK16)
                             part[1][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                 (__attribute__((address_space(3))) bf16x4 *)(src + IMG_ELEMS));
                     }
                     const bf16x8 Ah = __builtin_shufflevector(part[0][0], part[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     bf16x8 Al;
-                    if (PREC == 0) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (PREC == 0 && LAY != LAY_BLK16) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         if (PREC == 0) {
-                            acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], acc[R][tt], 0, 0, 0);
+                            if (LAY != LAY_BLK16) acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], acc[R][tt], 0, 0, 0);
                             acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[tt], acc[R][tt], 0, 0, 0);
                         }
                         acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[tt], acc[R][tt], 0, 0, 0);
@@ -1016,80 +1060,84 @@ inline bool fused_shape_ok(const cdl_geom *g)
     if (g->C != 1 || g->D != 1 || g->Pd != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
     if (g->Ph != g->Pw || g->Ph > 7 || (g->Ph & 1) == 0 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
     if (g->M != 32 && g->M != 64) return false;
-    if ((size_t)g->M * g->H * g->W * 4 >= ((size_t)1 << 31)) return false;   // per-image buffer descriptor range
+    if (blk_image_elems(g->M, g->H, g->W) * 4 >= ((size_t)1 << 31)) return false;   // per-image buffer descriptor range
     return true;
 }
 
-inline int debug_flags()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("CDL_FUSED_DEBUG"); v = e ? atoi(e) : 0; }
-    return v;
-}
+inline int debug_flags() { return cdl_opts().fused_debug; }
 
 inline int tiles_x(const cdl_geom *g) { return (g->W + TW - 1) / TW; }
 inline int tiles_y(const cdl_geom *g) { return (g->H + TH - 1) / TH; }
 
-template <int MT, int PREC, int MODE, bool WIDE>
+// `precision` argument of the entry points: bits 0-3 arithmetic (0 split-bf16 x3, 1 plain bf16), bit 4
+// CDL_TILES_REVERSED, bits 5-6 layout of the fat INPUT(s), bits 7-8 layout of the fat OUTPUT (LAY_*)
+struct Flags {
+    int prec, rev, lin, lout;
+    bool ok;
+};
+inline Flags parse_flags(int precision)
+{
+    Flags f;
+    f.prec = precision & 15;
+    f.rev = (precision >> 4) & 1;
+    f.lin = (precision >> 5) & 3;
+    f.lout = (precision >> 7) & 3;
+    f.ok = (precision >> 9) == 0 && (f.prec == 0 || f.prec == 1) && f.lin <= LAY_BLK16 && f.lout <= LAY_BLK16;
+    return f;
+}
+
+template <int MT, int PREC, int MODE, int LIN, int LOUT>
 int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
 {
-    static bool attr_done = false;               // idempotent; a race only repeats the call
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_stage<MT, PREC, MODE, WIDE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_STAGE);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
-    k_stage<MT, PREC, MODE, WIDE><<<grid, NT, LDS_STAGE, st>>>(p);
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT>, LDS_STAGE)) return rc;
+    k_stage<MT, PREC, MODE, LIN, LOUT><<<grid, NT, LDS_STAGE, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+// The layout pairs the sweeps and the step-wise entry points use: same layout on both sides, or NCHW on one
+// side (z_K leaves a sweep as NCHW, a user gradient enters one as NCHW).  MODE_FIRST has no fat input.
+template <int MT, int PREC, int MODE>
+int launch_stage_lay(const FusedParams &p, int lin, int lout, dim3 grid, hipStream_t st)
+{
+    if (MODE == MODE_FIRST) lin = lout;
+#define CDL_LAY_CASE(a, b) if (lin == a && lout == b) return launch_stage_one<MT, PREC, MODE, a, b>(p, grid, st)
+    CDL_LAY_CASE(LAY_NCHW, LAY_NCHW);
+    CDL_LAY_CASE(LAY_BLK, LAY_BLK);
+    CDL_LAY_CASE(LAY_BLK16, LAY_BLK16);
+    if constexpr (MODE == MODE_FWD) {
+        CDL_LAY_CASE(LAY_BLK, LAY_NCHW);
+        CDL_LAY_CASE(LAY_BLK16, LAY_NCHW);
+    }
+    if constexpr (MODE == MODE_BWD) {
+        CDL_LAY_CASE(LAY_NCHW, LAY_BLK);
+        CDL_LAY_CASE(LAY_NCHW, LAY_BLK16);
+    }
+#undef CDL_LAY_CASE
+    return CDL_EUNSUPPORTED;
+}
+
 template <int MT, int PREC>
-int launch_stage(const FusedParams &p, int mode, dim3 grid, hipStream_t st)
+int launch_stage(const FusedParams &p, int mode, int lin, int lout, dim3 grid, hipStream_t st)
 {
-    // The 16-byte path is opt-in (CDL_FUSED_WIDE=1): measured on MI355X it is SLOWER than 4-byte
-    // accesses (fwd 0.76 vs 0.49 ms, bwd 1.06 vs 0.66 ms at the cfg2 shape) -- a quad's 16-B pieces
-    // sit in 4 different channel rows, so one dwordx4 instruction touches 8 half-lines per 16-lane pass
-    // where the dword form touches 2 whole lines.  Kept (bit-identical, tested) as the access shape a
-    // bf16-storage mode will need.
-    const bool wide = (p.W & 3) == 0 && getenv("CDL_FUSED_WIDE") != nullptr;
-    if (wide) {
-        if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD, true>(p, grid, st);
-        if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST, true>(p, grid, st);
-        return launch_stage_one<MT, PREC, MODE_BWD, true>(p, grid, st);
-    }
-    if (mode == MODE_FWD) return launch_stage_one<MT, PREC, MODE_FWD, false>(p, grid, st);
-    if (mode == MODE_FIRST) return launch_stage_one<MT, PREC, MODE_FIRST, false>(p, grid, st);
-    return launch_stage_one<MT, PREC, MODE_BWD, false>(p, grid, st);
+    if (mode == MODE_FWD) return launch_stage_lay<MT, PREC, MODE_FWD>(p, lin, lout, grid, st);
+    if (mode == MODE_FIRST) return launch_stage_lay<MT, PREC, MODE_FIRST>(p, lin, lout, grid, st);
+    return launch_stage_lay<MT, PREC, MODE_BWD>(p, lin, lout, grid, st);
 }
 
-inline int cu_count()
-{
-    static int n = 0;                            // one GPU per process (one rank per GPU)
-    if (n <= 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
-}
-
-int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, int precision, hipStream_t st)
+int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, const Flags &f, hipStream_t st)
 {
     // persistent workgroups: one per CU (128 KB of LDS each), striding over the tiles
     const size_t tiles = (size_t)p.N * p.tilesX * p.tilesY;
-    size_t cus = (size_t)cu_count();
-    if (const char *e = getenv("CDL_FUSED_GRID")) {          // experiments only: fewer persistent workgroups
-        const int v = atoi(e);
-        if (v > 0 && (size_t)v < cus) cus = (size_t)v;
-    }
+    size_t cus = (size_t)cdl_cu_count();
+    const int cap = cdl_opts().fused_grid;                   // experiments only: fewer persistent workgroups
+    if (cap > 0 && (size_t)cap < cus) cus = (size_t)cap;
     dim3 grid((unsigned)(tiles < cus ? tiles : cus));
-    if (g->M == 64) return precision == 0 ? launch_stage<2, 0>(p, mode, grid, st) : launch_stage<2, 1>(p, mode, grid, st);
-    return precision == 0 ? launch_stage<1, 0>(p, mode, grid, st) : launch_stage<1, 1>(p, mode, grid, st);
+    if (g->M == 64)
+        return f.prec == 0 ? launch_stage<2, 0>(p, mode, f.lin, f.lout, grid, st)
+                           : launch_stage<2, 1>(p, mode, f.lin, f.lout, grid, st);
+    return f.prec == 0 ? launch_stage<1, 0>(p, mode, f.lin, f.lout, grid, st)
+                       : launch_stage<1, 1>(p, mode, f.lin, f.lout, grid, st);
 }
 
 int wgrad_grid(const cdl_geom *g)
@@ -1098,27 +1146,22 @@ int wgrad_grid(const cdl_geom *g)
     return (int)(tiles < 512 ? tiles : 512);
 }
 
-template <int MT, int PREC, bool WIDE>
+template <int MT, int PREC, int LAY>
 int launch_wgrad_one(const WgradParams &p, int G, hipStream_t st)
 {
     const size_t lds = (size_t)WG_THIN_BYTES + (size_t)8 * MT * 2 * IMG_ELEMS * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_wgrad2d<MT, PREC, WIDE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
-    k_wgrad2d<MT, PREC, WIDE><<<G, 512, lds, st>>>(p);
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgrad2d<MT, PREC, LAY>, (int)lds)) return rc;
+    k_wgrad2d<MT, PREC, LAY><<<G, 512, lds, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
 template <int MT, int PREC>
-int launch_wgrad(const WgradParams &p, int G, hipStream_t st)
+int launch_wgrad(const WgradParams &p, int lay, int G, hipStream_t st)
 {
-    if ((p.W & 3) == 0 && getenv("CDL_FUSED_WIDE")) return launch_wgrad_one<MT, PREC, true>(p, G, st);
-    return launch_wgrad_one<MT, PREC, false>(p, G, st);
+    if (lay == LAY_BLK) return launch_wgrad_one<MT, PREC, LAY_BLK>(p, G, st);
+    if (lay == LAY_BLK16) return launch_wgrad_one<MT, PREC, LAY_BLK16>(p, G, st);
+    return launch_wgrad_one<MT, PREC, LAY_NCHW>(p, G, st);
 }
 
 }  // namespace
@@ -1150,6 +1193,15 @@ int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P
     return 0;
 }
 
+size_t cdl_fused2d_code_bytes(const cdl_geom *g, int layout)
+{
+    if (!fused_shape_ok(g) || layout < 0 || layout > LAY_BLK16) return 0;
+    const size_t per = layout == LAY_NCHW ? lay_image_bytes<LAY_NCHW>(g->M, g->H, g->W)
+                     : layout == LAY_BLK ? lay_image_bytes<LAY_BLK>(g->M, g->H, g->W)
+                                         : lay_image_bytes<LAY_BLK16>(g->M, g->H, g->W);
+    return (size_t)g->N * per;
+}
+
 size_t cdl_fused2d_map_words(const cdl_geom *g)
 {
     if (!fused_shape_ok(g)) return 0;
@@ -1172,17 +1224,16 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
-    const int rev = (precision >> 4) & 1;
-    precision &= ~CDL_TILES_REVERSED;
-    if (precision != 0 && precision != 1) return CDL_EINVAL;
+    const Flags f = parse_flags(precision);
+    if (!f.ok) return CDL_EINVAL;
     FusedParams p = {};
-    p.rev = rev;
+    p.rev = f.rev;
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = sgn; p.do_synth = 1; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
-    return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, precision, S(stream));
+    return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, f, S(stream));
 }
 
 int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
@@ -1192,17 +1243,16 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
-    const int rev = (precision >> 4) & 1;
-    precision &= ~CDL_TILES_REVERSED;
-    if (precision != 0 && precision != 1) return CDL_EINVAL;
+    const Flags f = parse_flags(precision);
+    if (!f.ok) return CDL_EINVAL;
     FusedParams p = {};
-    p.rev = rev;
+    p.rev = f.rev;
     p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
     p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; p.dbg = debug_flags();
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
-    return dispatch_stage(g, p, MODE_BWD, precision, S(stream));
+    return dispatch_stage(g, p, MODE_BWD, f, S(stream));
 }
 
 int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c, float *dt0,
@@ -1228,11 +1278,10 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!workspace || (!X0 && !X1)) return CDL_EINVAL;
     if ((X0 && (!T0 || !dw0)) || (X1 && (!T1 || !dw1))) return CDL_EINVAL;
-    const int rev = (precision >> 4) & 1;
-    precision &= ~CDL_TILES_REVERSED;
-    if (precision != 0 && precision != 1) return CDL_EINVAL;
+    const Flags f = parse_flags(precision);
+    if (!f.ok) return CDL_EINVAL;
     WgradParams p = {};
-    p.rev = rev;
+    p.rev = f.rev;
     p.X[0] = X0; p.T[0] = T0; p.X[1] = X1; p.T[1] = T1;
     p.partial = workspace;
     p.N = g->N; p.H = g->H; p.W = g->W;
@@ -1240,8 +1289,8 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     p.numTiles = p.N * p.tilesX * p.tilesY;
     const int G = wgrad_grid(g);
     int rc;
-    if (g->M == 64) rc = precision == 0 ? launch_wgrad<2, 0>(p, G, S(stream)) : launch_wgrad<2, 1>(p, G, S(stream));
-    else rc = precision == 0 ? launch_wgrad<1, 0>(p, G, S(stream)) : launch_wgrad<1, 1>(p, G, S(stream));
+    if (g->M == 64) rc = f.prec == 0 ? launch_wgrad<2, 0>(p, f.lin, G, S(stream)) : launch_wgrad<2, 1>(p, f.lin, G, S(stream));
+    else rc = f.prec == 0 ? launch_wgrad<1, 0>(p, f.lin, G, S(stream)) : launch_wgrad<1, 1>(p, f.lin, G, S(stream));
     if (rc) return rc;
     const int total = 2 * g->M * g->Ph * g->Pw;
     k_wgrad_reduce<<<(total + 31) / 32, 1024, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
@@ -1272,12 +1321,16 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
  * bench.py turns it on for a few steps to report the in-step average duration of the three fat kernels
  * (isolated re-launches of one kernel miss the cache state the step leaves behind).  Off: no events. */
 namespace {
+// Process-wide and mutex-guarded: the one piece of state of this file, used by bench.py only.  Events are
+// recorded on whichever stream the timed sweep runs on; pairs of different devices are kept apart by the
+// device they were created on (an event can only be recorded on its own device's streams).
 struct TimingState {
-    bool on = false;
-    std::vector<hipEvent_t> pool;          // start/stop pairs, in launch order
-    std::vector<int> cls;                  // class of pair i: 0 forward stage (k >= 1), 1 reverse stage,
+    std::mutex mu;
+    std::atomic<bool> on{false};
+    struct Pair { hipEvent_t start, stop; int cls, dev; };
+    std::vector<Pair> pairs;               // in launch order; class 0 forward stage (k >= 1), 1 reverse stage,
                                            // 2 filter gradients, 3 first forward stage (k = 0: no fat read)
-    size_t used = 0;
+    std::vector<std::pair<hipEvent_t, int>> spare;     // recycled events with their device
 };
 TimingState g_timing;
 
@@ -1286,16 +1339,21 @@ struct TimingScope {
     hipEvent_t stop = nullptr;
     TimingScope(int c, hipStream_t s) : st(s)
     {
-        if (!g_timing.on) return;
-        while (g_timing.pool.size() < 2 * (g_timing.used + 1)) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
-            g_timing.pool.push_back(e);
+        if (!g_timing.on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lk(g_timing.mu);
+        const int dev = cdl_current_device();
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (int i = 0; i < 2; ++i) {
+            for (size_t k = 0; k < g_timing.spare.size() && !ev[i]; ++k)
+                if (g_timing.spare[k].second == dev) {
+                    ev[i] = g_timing.spare[k].first;
+                    g_timing.spare.erase(g_timing.spare.begin() + k);
+                }
+            if (!ev[i] && hipEventCreate(&ev[i]) != hipSuccess) return;
         }
-        (void)hipEventRecord(g_timing.pool[2 * g_timing.used], st);
-        stop = g_timing.pool[2 * g_timing.used + 1];
-        g_timing.cls.push_back(c);
-        ++g_timing.used;
+        (void)hipEventRecord(ev[0], st);
+        stop = ev[1];
+        g_timing.pairs.push_back({ev[0], ev[1], c, dev});
     }
     ~TimingScope()
     {
@@ -1306,10 +1364,14 @@ struct TimingScope {
 
 extern "C" int cdl_fused2d_timing(int enable)
 {
-    g_timing.on = enable != 0;
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.on.store(enable != 0, std::memory_order_relaxed);
     if (enable) {
-        g_timing.used = 0;
-        g_timing.cls.clear();
+        for (auto &pr : g_timing.pairs) {
+            g_timing.spare.push_back({pr.start, pr.dev});
+            g_timing.spare.push_back({pr.stop, pr.dev});
+        }
+        g_timing.pairs.clear();
     }
     return 0;
 }
@@ -1317,14 +1379,15 @@ extern "C" int cdl_fused2d_timing(int enable)
 extern "C" int cdl_fused2d_timing_read(double *ms_sum, int *count)
 {
     if (!ms_sum || !count) return CDL_EINVAL;
+    std::lock_guard<std::mutex> lk(g_timing.mu);
     for (int c = 0; c < 4; ++c) { ms_sum[c] = 0.0; count[c] = 0; }
-    for (size_t i = 0; i < g_timing.used; ++i) {
+    for (auto &pr : g_timing.pairs) {
         float ms = 0.0f;
-        hipError_t e = hipEventSynchronize(g_timing.pool[2 * i + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_timing.pool[2 * i], g_timing.pool[2 * i + 1]);
+        hipError_t e = hipEventSynchronize(pr.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.start, pr.stop);
         if (e != hipSuccess) return -(int)e;
-        ms_sum[g_timing.cls[i]] += ms;
-        ++count[g_timing.cls[i]];
+        ms_sum[pr.cls] += ms;
+        ++count[pr.cls];
     }
     return 0;
 }
@@ -1358,11 +1421,10 @@ static int prep_pairs(const float *const *w1, const float *const *w2, int K, int
     return 0;
 }
 
-static int snake_enabled()
-{
-    static const int on = [] { const char *e = getenv("CDL_FUSED_SNAKE"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on;
-}
+static int snake_enabled() { return cdl_opts().fused_snake; }
+
+// Sweeps: CDL_LAYOUT_IN(L) in `precision` selects the layout L of the tensors that stay inside the sweeps --
+// z_1 .. z_{K-1} (z[0..K-2]) and the du ping-pong buffers; z_K (z[K-1]) and g_z are always NCHW fp32.
 
 int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
                         const float *const *wA, const float *const *wB, float *const *z, float *const *r,
@@ -1373,6 +1435,9 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
     if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
     const size_t nm = (size_t)g->N * g->M;
     const int snake = snake_enabled();
+    const Flags f = parse_flags(precision);
+    if (!f.ok || f.lout != 0) return CDL_EINVAL;
+    const int L = f.lin;
     const float *thin = yp;
     const size_t fb = cdl_fused2d_frag_bytes(g->M);
     int rc = prep_pairs(wA, wB, K, 1, frags, g->M, g->Ph, S(stream));       // (A_k, B_{k+1}) for every k, one launch
@@ -1383,7 +1448,9 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
             TimingScope ts(k ? 0 : 3, S(stream));
             rc = cdl_fused2d_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k],
                                       patches, maps ? maps[k] : nullptr,
-                                      precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+                                      f.prec | CDL_LAYOUT_IN(L) | CDL_LAYOUT_OUT(k == K - 1 ? LAY_NCHW : L) |
+                                          ((k & 1) && snake ? CDL_TILES_REVERSED : 0),
+                                      stream);
         }
         if (rc) return rc;
         if (k < K - 1) {
@@ -1410,12 +1477,15 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
         return CDL_EINVAL;
     const int M = g->M;
     float *du[2] = {du0, du1};
+    const Flags f = parse_flags(precision);
+    if (!f.ok || f.lout != 0) return CDL_EINVAL;
+    const int L = f.lin;
     // the forward's last launch ran in direction (K-1)&1: stages take that one, filter gradients the other
     const int sdir = snake_enabled() ? (((K - 1) & 1) ? CDL_TILES_REVERSED : 0) : 0;
     const int wdir = snake_enabled() ? (sdir ^ CDL_TILES_REVERSED) : 0;
-    const int sprec = precision | sdir, wprec = precision | wdir;
+    const int sprec = f.prec | sdir, wprec = f.prec | wdir;
     int rc = cdl_fused2d_wgrad(g, z[K - 1], g_xp, 1.0f, dB[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
-                               wprec, stream);                           // dB_0 = z_K (x) dL/d(D z_K)
+                               wprec, stream);                           // dB_0 = z_K (x) dL/d(D z_K); z_K is NCHW
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
     const size_t fb = cdl_fused2d_frag_bytes(M);
@@ -1426,7 +1496,8 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
         float *duk = du[flip];
         {
             TimingScope ts(1, S(stream));
-            rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1, sprec, stream);
+            rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
+                                       sprec | CDL_LAYOUT_IN(k == K - 1 ? LAY_NCHW : L) | CDL_LAYOUT_OUT(L), stream);
         }
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
@@ -1436,11 +1507,13 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
             if (rc) return rc;
             {
                 TimingScope ts(2, S(stream));
-                rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wprec, stream);
+                rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws,
+                                       wprec | CDL_LAYOUT_IN(L), stream);
             }
             thin = q;
         } else {
-            rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws, wprec, stream);
+            rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
+                                   wprec | CDL_LAYOUT_IN(L), stream);
         }
         if (rc) return rc;
         base = duk;

@@ -1,0 +1,881 @@
+// Fused ISTA iteration on the matrix cores for the shapes the 2-D flagship kernel (cdl_fused2d.hip) does not take:
+// any number of image channels C, 2-D or 3-D (depth taps Pd), unit stride, square filter planes P in {3, 5, 7},
+// M <= 64 -- BASELINE configs[2] (CDLNetVideo K=20 M=48 P=5x5x5) and configs[3] (JDD: C=3, M=64, P=7, Bayer mask).
+// Reference: the loop bodies model/net.py:87 and :205,  z = ST(z - A_k(mask * B_k z - yp), tau_k).
+//
+// Same fusion boundary as cdl_fused2d.hip: the launch is cut where the tensor is THIN (C channels), never where it
+// is fat (M channels):
+//
+//     launch k :  r_k (thin) , z_k (fat)  ->  z_{k+1} (fat) , partial B_{k+1} z_{k+1} (thin patches)
+//
+// so every fat tensor crosses HBM exactly once in and once out per iteration, with no halo; the (P-1)-wide halo in
+// y, x and depth lives on the thin residual.  Per 32-pixel row block of a wave:
+//
+//   analysis   acc[ch][px]   = sum_k W_A[ch][k] * im2col(r)[k][px]     k = (c, kd, ki, kj): C*Pd*P*P taps, padded to 16;
+//                                                                      im2col gathered from bf16 hi/lo planes in LDS
+//                                                                      through a tap -> offset table
+//   epilogue   z'            = ST(z -/+ acc, tau) -> global            (reverse mode: du = [z' != 0] (du' + acc), dtau)
+//   synthesis  col_g[tap][px] = sum_ch W_B^T[g][tap][ch] * z'[ch][px]  per group g = (c, kd); z' fed straight from the
+//                                                                      accumulator registers (no LDS)
+//   col2im     column direction by a Horner chain of DPP wave shifts (taps of a filter row are packed so that they sit
+//              in known registers / lane halves), row direction in a P-row register ring per group
+//
+// A wave writes its (RB + P - 1) x (32 + P - 1) partial patch per group into its PRIVATE LDS patch (no cross-wave
+// hazard inside the row loop); at the end of a tile the 8 wave patches are summed in a fixed order into the tile's
+// patch, which goes to global memory; k_assemble_g sums the overlapping tile patches and depth taps in a fixed order and
+// applies alpha, mask and -yp.  Everything is order-fixed: results are bit-reproducible, no atomics.
+//
+// fp32-grade accuracy on the bf16 matrix cores by the hi/lo split of cdl_fused2d.hip (3 MFMAs per product).
+// Arithmetic intensity: 93 (cfg3) / 132 (cfg4) MFMA instructions per 32 voxels against 12-16 KB of fat traffic: this
+// kernel needs ~50 % matrix-core utilisation to be HBM-bound (the 2-D flagship kernel: 16 %).
+#include <type_traits>
+#include <vector>
+
+#include "cdl_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int WX = 2, WY = 4, NW = WX * WY, NT = 64 * NW;   // 8 waves: 2 (x) x 4 (y)
+constexpr int RB = 4;                                      // image rows per wave
+constexpr int TW = 32 * WX, TH = RB * WY;                  // 64 x 16 pixel tile of one (n, depth) plane
+constexpr int OOB = 0x7fff0000;
+// groups g = (c, kd) are a template parameter (their col2im rings live in registers): G = C * Pd in {1, 3, 5, 7}
+
+enum { MODE_FWD = 0, MODE_FIRST = 1, MODE_BWD = 2 };
+
+// ---- tap packing of the synthesis-like GEMM's M dimension ------------------------------------------------------
+// Row t of a 32-row accumulator tile sits in register v = 4*((t>>3)&3) + (t&3) of lane half h = (t>>2)&1.  The taps
+// (i, j) of a P x P filter plane are assigned rows so that the column-direction col2im is a short static sequence:
+// P = 3, 7: t = 8 i + j (as cdl_fused2d.hip); P = 5: 25 taps packed into ONE 32-row tile (8i + j would need two).
+template <int P> __host__ __device__ constexpr int tap_slot(int i, int j)
+{
+    if (P == 5) return (i < 4 && j < 4) ? 8 * i + j : (i < 4 ? 8 * i + 4 : (j < 4 ? 8 * j + 5 : 6));
+    return 8 * i + j;
+}
+template <int P> struct TapTiles { static constexpr int RT = (P == 7) ? 2 : 1; };
+
+struct GParams {
+    const float *r;          // (N,C,D,H,W) thin input of the analysis-like half
+    const float *zin;        // (N,M,D,H,W) or nullptr
+    unsigned *map;           // (N,4,D,H,W) support / sign bit planes (forward: written when given; reverse: read)
+    float *zout;             // (N,M,D,H,W)
+    const float *tau;        // forward: (N,M)
+    float *dtau;             // reverse: (tiles, M) partial sums of -sign(z') * du
+    const uint4 *frags;      // prepared weights (k_prep_g)
+    float *patches;          // (tiles, G, PY, PX)
+    float sgn;
+    int do_synth;
+    int N, C, M, D, H, W, Pd, tilesX, tilesY, KS, rev;
+};
+
+__device__ __forceinline__ float wave_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+// lanes 0..31 receive the value of lanes 32..63 (which receive 0); see cdl_fused2d.hip for why this is inline asm
+__device__ __forceinline__ float upper_half_to_lower(float v)
+{
+    float lo = 0.0f;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "+v"(lo));
+    return lo;
+}
+
+// Sum over the 32 pixel lanes of each half-wave of N per-lane values (N = 16 or 32), leaving total #i on lane c with
+// c mod N == i (cdl_fused2d.hip)
+template <int N>
+struct LaneTransposeSum {
+    static __device__ __forceinline__ float run(const float (&v)[N], int c)
+    {
+        constexpr int n = N / 2;
+        const bool up = (c & n) != 0;
+        float w[n];
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const float keep = up ? v[k + n] : v[k];
+            const float send = up ? v[k] : v[k + n];
+            w[k] = keep + __shfl_xor(send, n, 64);
+        }
+        return LaneTransposeSum<n>::run(w, c);
+    }
+};
+template <>
+struct LaneTransposeSum<1> {
+    static __device__ __forceinline__ float run(const float (&v)[1], int) { return v[0]; }
+};
+
+// ---- weight preparation ------------------------------------------------------------------------------------------
+// fragment list of one (analysis bank wA, synthesis bank wB) pair, 16-byte lane entries:
+//   [A hi | A lo] : (R, ks)            lane (row ch = 32R + (lane&31), h): taps k = 16ks + 8h + e of wA[ch] in its own
+//                                       memory order k = ((c*Pd + kd)*P + ki)*P + kj (zero beyond M or K)
+//   [B hi | B lo] : (g, Rt, q = 2R + s) lane (row t = 32Rt + (lane&31), h), element e: channel
+//                                       32R + 16s + 8(e>>2) + 4h + (e&3) of wB[.][c][kd][tap of slot t] -- the k order
+//                                       in which an accumulator tile presents itself as the next MFMA's B operand
+template <int P>
+__device__ __forceinline__ void prep_one(const float *__restrict__ wA, const float *__restrict__ wB,
+                                         uint4 *__restrict__ out, int M, int C, int Pd, int MT, int KS, int KQ, int t)
+{
+    constexpr int RT = TapTiles<P>::RT;
+    const int G = C * Pd, K = G * P * P;
+    const int FA = MT * KS, FB = G * RT * KQ;
+    if (t >= (FA + FB) * 64) return;
+    const int lane = t & 63, f = t >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    float v[8];
+    if (f < FA) {
+        const int R = f / KS, ks = f % KS;
+        const int ch = 32 * R + row;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * h + e;
+            v[e] = (ch < M && k < K) ? wA[(size_t)ch * K + k] : 0.0f;
+        }
+    } else {
+        int q = f - FA;
+        const int kq = q % KQ; q /= KQ;
+        const int Rt = q % RT, g = q / RT;
+        const int slot = 32 * Rt + row;
+        int tap = -1;                                       // (i, j) whose slot this is
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j)
+                if (tap_slot<P>(i, j) == slot) tap = i * P + j;
+        const int R = kq >> 1, s = kq & 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 32 * R + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+            v[e] = (tap >= 0 && ch < M) ? wB[((size_t)ch * G + g) * (P * P) + tap] : 0.0f;
+        }
+    }
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        hi[e] = hh;
+        lo[e] = (__bf16)(v[e] - (float)hh);
+    }
+    uint4 *hd, *ld;
+    if (f < FA) { hd = out + (size_t)f * 64; ld = out + (size_t)(FA + f) * 64; }
+    else { hd = out + (size_t)(2 * FA + (f - FA)) * 64; ld = out + (size_t)(2 * FA + FB + (f - FA)) * 64; }
+    hd[lane] = __builtin_bit_cast(uint4, hi);
+    ld[lane] = __builtin_bit_cast(uint4, lo);
+}
+
+constexpr int PREP_BATCH = 32;
+struct PrepBatch {
+    const float *wA[PREP_BATCH];
+    const float *wB[PREP_BATCH];
+};
+template <int P>
+__global__ void k_prep_g(PrepBatch b, uint4 *__restrict__ out, int frag_uint4, int M, int C, int Pd, int MT, int KS, int KQ)
+{
+    prep_one<P>(b.wA[blockIdx.y], b.wB[blockIdx.y], out + (size_t)blockIdx.y * frag_uint4, M, C, Pd, MT, KS, KQ,
+                blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---- the stage kernel --------------------------------------------------------------------------------------------
+// LDS carve (bytes), see lds_bytes(): [A frags][B frags][koff][thin hi][thin lo][wave patches][tau][tacc]
+struct Carve {
+    int wa, wb, koff, xh, xl, wp, tau, tacc, total;
+};
+template <int P>
+__host__ __device__ inline Carve carve(int MT, int KS, int KQ, int G, int prec)
+{
+    constexpr int RT = TapTiles<P>::RT;
+    constexpr int XH = TH + P - 1, XW = TW + P - 1, PS = ((XH * XW + 7) / 8) * 8;
+    constexpr int WPE = (RB + P - 1) * (32 + P - 1);
+    Carve c;
+    const int hl = prec == 0 ? 2 : 1;
+    c.wa = 0;
+    c.wb = c.wa + MT * KS * hl * 1024;
+    c.koff = c.wb + G * RT * KQ * hl * 1024;
+    c.xh = c.koff + KS * 16 * 4;
+    c.xl = c.xh + G * PS * 2;
+    c.wp = c.xl + (prec == 0 ? G * PS * 2 : 0);
+    c.wp = (c.wp + 15) & ~15;
+    c.tau = c.wp + NW * G * WPE * 4;
+    c.tacc = c.tau + 64 * 4;
+    c.total = c.tacc + NW * 64 * 4;
+    return c;
+}
+
+template <int P, int G, int MT, int MODE>
+__global__ __launch_bounds__(NT) void k_stage_g(GParams p)
+{
+    constexpr int PREC = 0;                                  // split-bf16 x3 (a plain-bf16 variant is not built)
+    constexpr int RT = TapTiles<P>::RT;
+    constexpr int HALO = P / 2;
+    constexpr int XH = TH + P - 1, XW = TW + P - 1, PS = ((XH * XW + 7) / 8) * 8;
+    constexpr int WPW = 32 + P - 1, WPH = RB + P - 1, WPE = WPH * WPW;      // wave patch
+    constexpr int PY = TH + P - 1, PX = TW + P - 1;                          // tile patch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KS = p.KS, M = p.M;
+    const int KQ = (M + 15) / 16;                            // 16-channel k-steps of the synthesis-like GEMM
+    const Carve cv = carve<P>(MT, KS, KQ, G, PREC);
+    const uint4 *wa = reinterpret_cast<const uint4 *>(smem + cv.wa);
+    const uint4 *wb = reinterpret_cast<const uint4 *>(smem + cv.wb);
+    int *koff = reinterpret_cast<int *>(smem + cv.koff);
+    __bf16 *xh = reinterpret_cast<__bf16 *>(smem + cv.xh);
+    __bf16 *xl = reinterpret_cast<__bf16 *>(smem + cv.xl);
+    float *wp_all = reinterpret_cast<float *>(smem + cv.wp);
+    float *tau_s = reinterpret_cast<float *>(smem + cv.tau);
+    float *tacc_s = reinterpret_cast<float *>(smem + cv.tacc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wxi = wid % WX, wyi = wid / WX;
+    const int c = lane & 31, h = lane >> 5;
+    const size_t HW = (size_t)p.H * p.W, DHW = (size_t)p.D * HW;
+    const int K = G * P * P;
+    const int FA = MT * KS, FB = G * RT * KQ;
+    const int numTiles = p.N * p.D * p.tilesY * p.tilesX;
+
+    // ---- once per workgroup: weight fragments and the tap -> LDS offset table
+    {
+        uint4 *wdst = reinterpret_cast<uint4 *>(smem);
+        if (PREC == 0) {
+            for (int i = tid; i < 2 * FA * 64; i += NT) wdst[i] = p.frags[i];
+            uint4 *bdst = reinterpret_cast<uint4 *>(smem + cv.wb);
+            for (int i = tid; i < 2 * FB * 64; i += NT) bdst[i] = p.frags[2 * FA * 64 + i];
+        } else {                                             // plain bf16: hi parts only
+            for (int i = tid; i < FA * 64; i += NT) wdst[i] = p.frags[i];
+            uint4 *bdst = reinterpret_cast<uint4 *>(smem + cv.wb);
+            for (int i = tid; i < FB * 64; i += NT) bdst[i] = p.frags[2 * FA * 64 + i];
+        }
+        for (int k = tid; k < KS * 16; k += NT) {
+            int o = 0;
+            if (k < K) {
+                const int kj = k % P;
+                const int q = k / P;
+                o = (q / P) * PS + (q % P) * XW + kj;       // plane (c*Pd + kd), row ki, column kj
+            }
+            koff[k] = o;
+        }
+    }
+    const int OFF_AL = FA, OFF_BL = FB;                      // lo fragments follow the hi ones (split3 only)
+    auto afrag = [&](int f) { return __builtin_bit_cast(bf16x8, wa[f * 64 + lane]); };
+    auto bfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wb[f * 64 + lane]); };
+    float *wp = wp_all + (size_t)wid * G * WPE;
+    const int up_addr = ((lane & 31) + 32) * 4;              // ds_bpermute byte address of the lane 32 above
+    const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
+    const int dhw4 = (int)DHW * 4;
+
+#pragma unroll 1
+    for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
+        int bid = p.rev ? numTiles - 1 - t : t;
+        const int tile = bid;
+        const int txi = bid % p.tilesX; bid /= p.tilesX;
+        const int tyi = bid % p.tilesY; bid /= p.tilesY;
+        const int zd = bid % p.D, n = bid / p.D;
+        const int tx0 = txi * TW, ty0 = tyi * TH;
+        __syncthreads();                                     // previous tile's readers are done (and the tables are in)
+        // ---- thin planes of this tile: plane g = (c, kd) is depth zd - Pd/2 + kd of channel c
+        for (int g = 0; g < G; ++g) {
+            const int kd = g % p.Pd, cc = g / p.Pd;
+            const int d = zd - p.Pd / 2 + kd;
+            const bool dok = d >= 0 && d < p.D;
+            const float *plane = p.r + (((size_t)n * p.C + cc) * p.D + (dok ? d : 0)) * HW;
+            for (int i = tid; i < XH * XW; i += NT) {
+                const int col = i % XW, row = i / XW;
+                const int yy = ty0 - HALO + row, xx = tx0 - HALO + col;
+                const float v = (dok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? plane[(size_t)yy * p.W + xx] : 0.0f;
+                const __bf16 hh = (__bf16)v;
+                xh[g * PS + i] = hh;
+                if (PREC == 0) xl[g * PS + i] = (__bf16)(v - (float)hh);
+            }
+        }
+        if (MODE != MODE_BWD && tid < 64) tau_s[tid] = tid < M ? p.tau[(size_t)n * M + tid] : 0.0f;
+        for (int i = lane; i < G * WPE; i += 64) wp[i] = 0.0f;          // this wave's private patch
+        __syncthreads();
+        // thresholds are >= 0 whenever project() runs (net.py:70); a negative one (3-D trainer, never projected)
+        // sends the whole tile through the general shrinkage -- wave-uniform, so the common case pays 3 instructions
+        // per element instead of 10
+        const bool tau_neg = MODE != MODE_BWD && __ballot(tau_s[lane] < 0.0f) != 0ull;
+
+        float ring[G][P];                                    // row-direction col2im sums, per group
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < P; ++i) ring[g][i] = 0.0f;
+        float tsum[MT * 16];                                 // reverse: per-lane partial threshold gradients
+#pragma unroll
+        for (int i = 0; i < MT * 16; ++i) tsum[i] = 0.0f;
+
+        const int x = tx0 + wxi * 32 + c;
+        const bool xok = x < p.W;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+            has_base ? const_cast<float *>(p.zin) + (size_t)n * M * DHW : p.zout, 0, has_base ? (int)(M * DHW * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            p.zout + (size_t)n * M * DHW, 0, (int)(M * DHW * 4), 0x00020000);
+        unsigned *const map_n = p.map ? p.map + (((size_t)n * 4 + 2 * h) * p.D + zd) * HW : nullptr;
+        const int lane_off = (int)((4 * h) * DHW + (size_t)zd * HW + x) * 4;
+
+#pragma unroll 1
+        for (int b = 0; b < RB; ++b) {
+            const int yl = wyi * RB + b, y = ty0 + yl;
+            const bool valid = xok && y < p.H;
+            const int voff = valid ? lane_off + y * p.W * 4 : OOB;
+            // channels >= M (M < 32 MT) are masked through the per-lane offset: the scalar channel offset does not
+            // take part in the buffer range check, so they must not reach the address at all
+            auto ch_off = [&](int chl) { return (chl + 4 * h < M) ? voff : OOB; };
+
+            // -- fat inputs of this block, issued first
+            float zc[MT][16];
+            if (MODE != MODE_FIRST) {
+#pragma unroll
+                for (int R = 0; R < MT; ++R)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        zc[R][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs_in, ch_off(32 * R + 8 * (v >> 2) + (v & 3)), (32 * R + 8 * (v >> 2) + (v & 3)) * dhw4, 0));
+            }
+            unsigned sup = 0, sgb = 0;
+            if (MODE == MODE_BWD && valid) {
+                sup = map_n[(size_t)y * p.W + x];
+                sgb = map_n[DHW + (size_t)y * p.W + x];
+            }
+
+            // -- analysis-like GEMM: im2col gathered through the offset table
+            const int pixbase = yl * XW + wxi * 32 + c;
+            f32x16 acc[MT];
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ++ks) {
+                const int4 o0 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h);
+                const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
+                const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                bf16x8 bh, bl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    bh[i] = xh[oo[i] + pixbase];
+                    if (PREC == 0) bl[i] = xl[oo[i] + pixbase];
+                }
+#pragma unroll
+                for (int R = 0; R < MT; ++R) {
+                    const bf16x8 ah = afrag(R * KS + ks);
+                    if (PREC == 0) {
+                        const bf16x8 al = afrag(OFF_AL + R * KS + ks);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
+                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
+                    }
+                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
+                }
+            }
+
+            __builtin_amdgcn_sched_barrier(0);
+            // -- epilogue: register v of tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
+            auto epilogue = [&](auto general_shrink) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int qv = 0; qv < 4; ++qv) {
+                    if (32 * R + 8 * qv >= M) {              // uniform: both channel quads of this register quad are padding
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[R][4 * qv + e] = 0.0f;
+                        continue;
+                    }
+                    float t4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (MODE != MODE_BWD) {
+                        const float4 tt = *reinterpret_cast<const float4 *>(&tau_s[32 * R + 8 * qv + 4 * h]);
+                        t4[0] = tt.x; t4[1] = tt.y; t4[2] = tt.z; t4[3] = tt.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = 4 * qv + e;
+                        const int chl = 32 * R + 8 * qv + e;             // + 4h folded into lane_off
+                        const bool live = valid && (chl + 4 * h < M);
+                        float zz;
+                        if (MODE == MODE_BWD) {
+                            const bool on = (sup >> (16 * R + v)) & 1u;   // never set for out-of-image lanes / padding channels
+                            zz = on ? zc[R][v] + acc[R][v] : 0.0f;
+                            tsum[16 * R + v] += ((sgb >> (16 * R + v)) & 1u) ? zz : -zz;      // -sign(z') * du
+                        } else {
+                            const float base = (MODE == MODE_FWD) ? zc[R][v] : 0.0f;
+                            const float u = fmaf(p.sgn, acc[R][v], base);
+                            // t >= 0: sign(u) relu(|u| - t) == u - clamp(u, -t, t), same rounding, NaN in u stays NaN
+                            zz = decltype(general_shrink)::value ? cdl_shrink(u, t4[e])
+                                                                 : u - __builtin_amdgcn_fmed3f(u, -t4[e], t4[e]);
+                            zz = live ? zz : 0.0f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), rs_out, ch_off(chl), chl * dhw4, 0);
+                        acc[R][v] = zz;
+                    }
+                }
+            };
+            if (tau_neg) epilogue(std::true_type{});         // wave-uniform
+            else epilogue(std::false_type{});
+            if (MODE != MODE_BWD && map_n) {                 // uniform: training forward only
+                unsigned ws = 0, wg = 0;
+#pragma unroll
+                for (int R = 0; R < MT; ++R)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float zz = acc[R][v];
+                        ws |= (zz != 0.0f ? 1u : 0u) << (16 * R + v);
+                        wg |= (__builtin_bit_cast(unsigned, zz) >> 31) << (16 * R + v);
+                    }
+                if (valid) {
+                    map_n[(size_t)y * p.W + x] = ws;
+                    map_n[DHW + (size_t)y * p.W + x] = wg;
+                }
+            }
+            if (MODE == MODE_BWD && !p.do_synth) continue;
+
+            __builtin_amdgcn_sched_barrier(0);
+            // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand; split once,
+            //    reused by every group
+            bf16x8 zh[2 * MT], zl[2 * MT];
+#pragma unroll
+            for (int q = 0; q < 2 * MT; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float val = acc[q >> 1][8 * (q & 1) + e];
+                    const __bf16 hh = (__bf16)val;
+                    zh[q][e] = hh;
+                    if (PREC == 0) zl[q][e] = (__bf16)(val - (float)hh);
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x16 Dt[RT];
+#pragma unroll
+                for (int Rt = 0; Rt < RT; ++Rt) {
+                    Dt[Rt] = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 2 * MT; ++q) {
+                        if (q >= KQ) break;                  // uniform: channels beyond M
+                        const int f = (g * RT + Rt) * KQ + q;
+                        const bf16x8 wh = bfrag(f);
+                        if (PREC == 0) {
+                            const bf16x8 wl = bfrag(OFF_BL + f);
+                            Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt[Rt], 0, 0, 0);
+                            Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt[Rt], 0, 0, 0);
+                        }
+                        Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh[q], Dt[Rt], 0, 0, 0);
+                    }
+                }
+                // -- col2im, column direction: for filter row i, sum over j of tap (i, j) shifted right by j lanes;
+                //    lane L (0 .. 32+P-2) ends with the contribution to output column x0 - HALO + L.  The P rows run as
+                //    independent Horner chains side by side (no DPP wait states to pad); taps that sit in the upper lane
+                //    half are fetched with one cross-lane read each.  Row direction: tap row i of image row y lands on
+                //    output row y - HALO + i = ring slot i.
+                float sr[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) sr[i] = 0.0f;
+#pragma unroll
+                for (int j = P - 1; j >= 0; --j)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        const int slot = tap_slot<P>(i, j);
+                        const int Rt = slot >> 5, v = 4 * ((slot >> 3) & 3) + (slot & 3), hh = (slot >> 2) & 1;
+                        float val = Dt[Rt][v];
+                        if (hh)                              // lanes 0..31 read lanes 32..63
+                            val = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up_addr, __builtin_bit_cast(int, val)));
+                        sr[i] = wave_shr1(sr[i]) + (h == 0 ? val : 0.0f);
+                    }
+#pragma unroll
+                for (int i = 0; i < P; ++i) ring[g][i] += sr[i];
+                // ring slot 0 is complete after this block: one plain LDS store per lane into the wave's own patch
+                if (lane < WPW) wp[g * WPE + b * WPW + lane] = ring[g][0];
+#pragma unroll
+                for (int i = 0; i + 1 < P; ++i) ring[g][i] = ring[g][i + 1];
+                ring[g][P - 1] = 0.0f;
+            }
+        }
+        // ---- the P-1 output rows below the wave's last image row are still in the ring
+        if (MODE != MODE_BWD || p.do_synth) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int i = 0; i + 1 < P; ++i)
+                    if (lane < WPW) wp[g * WPE + (RB + i) * WPW + lane] = ring[g][i];
+            }
+        }
+        if (MODE == MODE_BWD) {
+            const float tacc = LaneTransposeSum<MT * 16>::run(tsum, c) ;
+            float tot = tacc;
+            if (MT == 1) tot += __shfl_xor(tot, 16, 64);     // lanes c and c^16 hold halves of the same index
+            if (c < MT * 16) {
+                const int R = c >> 4, v = c & 15;
+                tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tot;
+            }
+        }
+        __syncthreads();                                     // every wave's patch (and tacc) is complete
+        if (MODE == MODE_BWD && tid < 64) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sacc += tacc_s[w * 64 + tid];
+            if (tid < M) p.dtau[(size_t)tile * M + tid] = sacc;
+        }
+        if (MODE != MODE_BWD || p.do_synth) {
+            // tile patch = fixed-order sum (wave row, then wave column) of the wave patches covering each element
+            float *patch = p.patches + (size_t)tile * G * (PY * PX);
+            for (int o = tid; o < G * PY * PX; o += NT) {
+                const int g = o / (PY * PX), rem = o % (PY * PX);
+                const int Y = rem / PX, X = rem % PX;
+                float sum = 0.0f;
+#pragma unroll
+                for (int wy = 0; wy < WY; ++wy) {
+                    const int ry = Y - wy * RB;
+                    if (ry < 0 || ry >= WPH) continue;
+#pragma unroll
+                    for (int wx = 0; wx < WX; ++wx) {
+                        const int rx = X - wx * 32;
+                        if (rx < 0 || rx >= WPW) continue;
+                        sum += wp_all[((size_t)(wy * WX + wx) * G + g) * WPE + ry * WPW + rx];
+                    }
+                }
+                patch[o] = sum;
+            }
+        }
+    }
+}
+
+// out[n,c,d,Y,X] = (mask ? mask : 1) * alpha * (sum over depth taps kd and covering tiles of the patches) - (sub ? sub : 0)
+template <int P>
+__global__ __launch_bounds__(256) void k_assemble_g(const float *__restrict__ patches, const float *__restrict__ mask,
+                                                    const float *__restrict__ sub, float alpha, float *__restrict__ out,
+                                                    int N, int C, int D, int H, int W, int Pd, int tilesX, int tilesY)
+{
+    constexpr int HALO = P / 2, PY = TH + P - 1, PX = TW + P - 1;
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= W) return;
+    int r = blockIdx.z;
+    const int d = r % D; r /= D;
+    const int c = r % C, n = r / C;
+    const int G = C * Pd;
+    const int ay = Y + HALO, ax = X + HALO;                  // position in the patch grid of tile 0
+    const int ty_hi = min(tilesY - 1, ay / TH), ty_lo = max(0, (ay - PY + TH) / TH);
+    const int tx_hi = min(tilesX - 1, ax / TW), tx_lo = max(0, (ax - PX + TW) / TW);
+    float sum = 0.0f;
+    for (int kd = 0; kd < Pd; ++kd) {
+        const int zd = d + Pd / 2 - kd;                      // the code depth whose tap kd lands on d
+        if (zd < 0 || zd >= D) continue;
+        const int g = c * Pd + kd;
+        for (int ty = ty_lo; ty <= ty_hi; ++ty)
+            for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                const size_t tile = (((size_t)n * D + zd) * tilesY + ty) * tilesX + tx;
+                sum += patches[((tile * G + g) * PY + (ay - ty * TH)) * PX + (ax - tx * TW)];
+            }
+    }
+    const size_t i = ((((size_t)n * C + c) * D + d) * H + Y) * W + X;
+    float v = alpha * sum;
+    if (mask) v *= mask[i];
+    if (sub) v -= sub[i];
+    out[i] = v;
+}
+
+// dt0[m] = sum over tiles; dt1[m] = sum_n c[n] * (sum over the tiles of sample n): fixed-order tree (cdl_fused2d.hip)
+__global__ __launch_bounds__(1024) void k_dtau_reduce_g(const float *__restrict__ partial, const float *__restrict__ c,
+                                                        float *__restrict__ dt0, float *__restrict__ dt1, int N,
+                                                        int per_img, int M)
+{
+    __shared__ float r0[256][4], r1[256][4];
+    const int mi = threadIdx.x & 3, part = threadIdx.x >> 2;
+    const int m = blockIdx.x * 4 + mi;
+    float a0 = 0.0f, a1 = 0.0f;
+    const int rows = N * per_img;
+    if (m < M)
+        for (int row = part; row < rows; row += 256) {
+            const float v = partial[(size_t)row * M + m];
+            a0 += v;
+            if (c) a1 = fmaf(c[row / per_img], v, a1);
+        }
+    r0[part][mi] = a0;
+    r1[part][mi] = a1;
+    __syncthreads();
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (part < stride) { r0[part][mi] += r0[part + stride][mi]; r1[part][mi] += r1[part + stride][mi]; }
+        __syncthreads();
+    }
+    if (part == 0 && m < M) { dt0[m] = r0[0][mi]; dt1[m] = r1[0][mi]; }
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct Plan {
+    int P, MT, KS, KQ, G, tilesX, tilesY;
+    size_t tiles, frag_uint4, patch_floats;
+};
+
+bool plan_for(const cdl_geom *g, Plan *pl)
+{
+    if (!cdl_geom_ok(g)) return false;
+    if (g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
+    if (g->Ph != g->Pw || (g->Ph != 3 && g->Ph != 5 && g->Ph != 7)) return false;
+    if ((g->Pd & 1) == 0 || g->pd != g->Pd / 2 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
+    if (g->M > 64 || g->M < 1) return false;
+    pl->P = g->Ph;
+    pl->G = g->C * g->Pd;
+    if (pl->G != 1 && pl->G != 3 && pl->G != 5 && pl->G != 7) return false;
+    if (g->Ph == 7 && pl->G == 7) return false;             // 49 ring registers on top of the tiles: spills to scratch
+    pl->MT = (g->M + 31) / 32;
+    pl->KS = (pl->G * g->Ph * g->Pw + 15) / 16;
+    pl->KQ = (g->M + 15) / 16;
+    pl->tilesX = (g->W + TW - 1) / TW;
+    pl->tilesY = (g->H + TH - 1) / TH;
+    pl->tiles = (size_t)g->N * g->D * pl->tilesX * pl->tilesY;
+    const int RT = g->Ph == 7 ? 2 : 1;
+    pl->frag_uint4 = (size_t)2 * (pl->MT * pl->KS + pl->G * RT * pl->KQ) * 64;
+    pl->patch_floats = pl->tiles * pl->G * (TH + g->Ph - 1) * (TW + g->Pw - 1);
+    if ((size_t)g->M * g->D * g->H * g->W * 4 >= ((size_t)1 << 31)) return false;      // per-sample buffer descriptor range
+    if (pl->tiles >= ((size_t)1 << 30) || g->H > 65535 || (size_t)g->N * g->C * g->D > 65535) return false;
+    int lds = 0;
+    if (g->Ph == 3) lds = carve<3>(pl->MT, pl->KS, pl->KQ, pl->G, 0).total;
+    if (g->Ph == 5) lds = carve<5>(pl->MT, pl->KS, pl->KQ, pl->G, 0).total;
+    if (g->Ph == 7) lds = carve<7>(pl->MT, pl->KS, pl->KQ, pl->G, 0).total;
+    if (lds > 160 * 1024) return false;
+    return true;
+}
+
+template <int P, int G, int MT, int MODE>
+int launch_one(const GParams &p, const Plan &pl, hipStream_t st)
+{
+    const int lds = carve<P>(MT, pl.KS, pl.KQ, G, 0).total;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage_g<P, G, MT, MODE>, lds)) return rc;
+    size_t cus = (size_t)cdl_cu_count();
+    const int cap = cdl_opts().fused_grid;
+    if (cap > 0 && (size_t)cap < cus) cus = (size_t)cap;
+    const unsigned grid = (unsigned)(pl.tiles < cus ? pl.tiles : cus);
+    k_stage_g<P, G, MT, MODE><<<grid, NT, lds, st>>>(p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <int P, int G, int MT>
+int launch_mode(const GParams &p, const Plan &pl, int mode, hipStream_t st)
+{
+    if (mode == MODE_FWD) return launch_one<P, G, MT, MODE_FWD>(p, pl, st);
+    if (mode == MODE_FIRST) return launch_one<P, G, MT, MODE_FIRST>(p, pl, st);
+    return launch_one<P, G, MT, MODE_BWD>(p, pl, st);
+}
+
+template <int P, int G>
+int launch_g(const GParams &p, const Plan &pl, int mode, hipStream_t st)
+{
+    return pl.MT == 2 ? launch_mode<P, G, 2>(p, pl, mode, st) : launch_mode<P, G, 1>(p, pl, mode, st);
+}
+
+template <int P>
+int launch_p(const GParams &p, const Plan &pl, int mode, hipStream_t st)
+{
+    if (pl.G == 1) return launch_g<P, 1>(p, pl, mode, st);
+    if (pl.G == 3) return launch_g<P, 3>(p, pl, mode, st);
+    if (pl.G == 5) return launch_g<P, 5>(p, pl, mode, st);
+    return launch_g<P, 7>(p, pl, mode, st);
+}
+
+int dispatch(const cdl_geom *g, GParams &p, const Plan &pl, int mode, int precision, hipStream_t st)
+{
+    p.rev = (precision >> 4) & 1;
+    if ((precision >> 5) != 0) return CDL_EINVAL;
+    if ((precision & 15) != 0) return CDL_EUNSUPPORTED;      // split-bf16 x3 only
+    p.N = g->N; p.C = g->C; p.M = g->M; p.D = g->D; p.H = g->H; p.W = g->W; p.Pd = g->Pd;
+    p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.KS = pl.KS;
+    if (pl.P == 3) return launch_p<3>(p, pl, mode, st);
+    if (pl.P == 5) return launch_p<5>(p, pl, mode, st);
+    return launch_p<7>(p, pl, mode, st);
+}
+
+// fragments of K (analysis-like, synthesis-like) pairs, pair k at frags + k * frag bytes
+int prep_pairs(const cdl_geom *g, const Plan &pl, const float *const *w1, const float *const *w2, int K, int shift2,
+               void *frags, hipStream_t st)
+{
+    const int threads = (int)(pl.frag_uint4 / 2);           // one thread per (fragment, lane); hi and lo together
+    for (int k0 = 0; k0 < K; k0 += PREP_BATCH) {
+        const int nb = K - k0 < PREP_BATCH ? K - k0 : PREP_BATCH;
+        PrepBatch b = {};
+        for (int i = 0; i < nb; ++i) {
+            const int k = k0 + i;
+            b.wA[i] = shift2 == 0 ? w1[(k + 1) % K] : w1[k];
+            b.wB[i] = shift2 == 0 ? w2[k] : w2[(k + 1) % K];
+        }
+        dim3 grid((unsigned)((threads + 255) / 256), (unsigned)nb);
+        uint4 *out = reinterpret_cast<uint4 *>(frags) + (size_t)k0 * pl.frag_uint4;
+        if (pl.P == 3) k_prep_g<3><<<grid, 256, 0, st>>>(b, out, (int)pl.frag_uint4, g->M, g->C, g->Pd, pl.MT, pl.KS, pl.KQ);
+        else if (pl.P == 5) k_prep_g<5><<<grid, 256, 0, st>>>(b, out, (int)pl.frag_uint4, g->M, g->C, g->Pd, pl.MT, pl.KS, pl.KQ);
+        else k_prep_g<7><<<grid, 256, 0, st>>>(b, out, (int)pl.frag_uint4, g->M, g->C, g->Pd, pl.MT, pl.KS, pl.KQ);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdl_fusedg_supported(const cdl_geom *g)
+{
+    Plan pl;
+    return plan_for(g, &pl) ? 1 : 0;
+}
+
+size_t cdl_fusedg_frag_bytes(const cdl_geom *g)
+{
+    Plan pl;
+    return plan_for(g, &pl) ? pl.frag_uint4 * 16 : 0;
+}
+
+size_t cdl_fusedg_patch_floats(const cdl_geom *g)
+{
+    Plan pl;
+    return plan_for(g, &pl) ? pl.patch_floats : 0;
+}
+
+size_t cdl_fusedg_tiles(const cdl_geom *g)
+{
+    Plan pl;
+    return plan_for(g, &pl) ? pl.tiles : 0;
+}
+
+size_t cdl_fusedg_map_words(const cdl_geom *g)
+{
+    Plan pl;
+    return plan_for(g, &pl) ? (size_t)g->N * 4 * g->D * g->H * g->W : 0;
+}
+
+int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (!wA || !wB || !frags) return CDL_EINVAL;
+    const float *a[1] = {wA}, *b[1] = {wB};
+    return prep_pairs(g, pl, a, b, 1, 1, frags, S(stream));
+}
+
+int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin, const float *tau, const void *frags,
+                        float sgn, float *zout, float *patches, unsigned *map_out, int precision, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
+    GParams p = {};
+    p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
+    p.frags = reinterpret_cast<const uint4 *>(frags);
+    p.patches = patches; p.sgn = sgn; p.do_synth = 1;
+    return dispatch(g, p, pl, zin ? MODE_FWD : MODE_FIRST, precision, S(stream));
+}
+
+int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
+                         const void *frags, float *du_out, float *patches, float *dtau_partial, int do_synth,
+                         int precision, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
+    if (do_synth && !patches) return CDL_EINVAL;
+    GParams p = {};
+    p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
+    p.frags = reinterpret_cast<const uint4 *>(frags);
+    p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0;
+    return dispatch(g, p, pl, MODE_BWD, precision, S(stream));
+}
+
+int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *mask, const float *sub, float alpha,
+                        float *out, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (!patches || !out) return CDL_EINVAL;
+    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
+#define CDL_ASM(P_) k_assemble_g<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
+    if (pl.P == 3) CDL_ASM(3); else if (pl.P == 5) CDL_ASM(5); else CDL_ASM(7);
+#undef CDL_ASM
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_fusedg_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c, float *dt0, float *dt1,
+                           void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
+    k_dtau_reduce_g<<<(g->M + 3) / 4, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N,
+                                                            g->D * pl.tilesX * pl.tilesY, g->M);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- whole sweeps (one C call each), the counterparts of cdl_fused2d_forward / _backward ------------------------ */
+int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
+                       const float *const *wA, const float *const *wB, float *const *z, float *const *r,
+                       unsigned *const *maps, float *xp, void *frags, float *patches, int precision, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
+    const size_t nm = (size_t)g->N * g->M;
+    const int snake = cdl_opts().fused_snake;
+    const float *thin = yp;
+    const size_t fb = pl.frag_uint4 * 16;
+    int rc = prep_pairs(g, pl, wA, wB, K, 1, frags, S(stream));             // (A_k, B_{k+1}) for every k
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
+        rc = cdl_fusedg_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k], patches,
+                                 maps ? maps[k] : nullptr, precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+        if (rc) return rc;
+        if (k < K - 1) {
+            rc = cdl_fusedg_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
+            thin = r[k];
+        } else {
+            rc = cdl_fusedg_assemble(g, patches, nullptr, nullptr, 1.0f, xp, stream);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* Reverse sweep: the fused stage produces du_k (one fat write), the threshold partials and the patches of q_k; the
+ * filter gradients dA_k = -du_k (x) r_k and dB_k = z_k (x) q_k come from the shape-generic cdl_wgrad (its matrix-core
+ * kernel where the shape has one).  wgrad_ws: cdl_wgrad_workspace_floats(g) floats. */
+int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *c,
+                        const float *const *wA, const float *const *wB, const float *const *z, const float *const *r,
+                        const unsigned *const *maps, const float *g_xp, const float *g_z, float *const *dA,
+                        float *const *dB, float *dt, float *du0, float *du1, float *q, void *frags, float *patches,
+                        float *dtau_partial, float *wgrad_ws, size_t wgrad_ws_floats, int precision, void *stream)
+{
+    Plan pl;
+    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    if (K < 1 || !yp || !wA || !wB || !z || !maps || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
+        !patches || !dtau_partial || (K > 1 && !r))
+        return CDL_EINVAL;
+    const int M = g->M;
+    float *du[2] = {du0, du1};
+    const int snake = cdl_opts().fused_snake;
+    const int sdir = snake ? (((K - 1) & 1) ? CDL_TILES_REVERSED : 0) : 0;
+    int rc = cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], wgrad_ws, wgrad_ws_floats, stream);      // dB_0 = z_K (x) dL/d(D z_K)
+    if (rc) return rc;
+    const float *thin = g_xp, *base = g_z;
+    const size_t fb = pl.frag_uint4 * 16;
+    rc = prep_pairs(g, pl, wB, wA, K, 0, frags, S(stream));                 // (B_{k+1}, A_k) for every k
+    if (rc) return rc;
+    for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
+        const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
+        float *duk = du[flip];
+        rc = cdl_fusedg_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
+                                  (precision & 15) | (((K - 1 - k) & 1) ? (sdir ^ CDL_TILES_REVERSED) : sdir), stream);
+        if (rc) return rc;
+        rc = cdl_fusedg_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
+        if (rc) return rc;
+        if (k >= 1) {
+            rc = cdl_fusedg_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
+            if (rc) return rc;
+            rc = cdl_wgrad(g, duk, nullptr, r[k - 1], -1.0f, dA[k], wgrad_ws, wgrad_ws_floats, stream);
+            if (rc) return rc;
+            rc = cdl_wgrad(g, z[k - 1], nullptr, q, 1.0f, dB[k], wgrad_ws, wgrad_ws_floats, stream);
+            thin = q;
+        } else {
+            rc = cdl_wgrad(g, duk, nullptr, yp, 1.0f, dA[0], wgrad_ws, wgrad_ws_floats, stream);
+        }
+        if (rc) return rc;
+        base = duk;
+    }
+    return 0;
+}
+
+}  // extern "C"

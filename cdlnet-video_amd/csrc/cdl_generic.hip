@@ -571,22 +571,18 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
 // enough; CDL_MFMA_ANALYSIS=0 selects the VALU kernels (read per call)
 static bool mfma_analysis_enabled(const cdl_geom *g)
 {
-    const char *e = getenv("CDL_MFMA_ANALYSIS");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
-    return true;
+    return cdl_opts().mfma_analysis != 0;
 }
 
 // the dense many-channel tier (cdl_dense_mfma.hip; C >= 16 on both sides, unit stride); CDL_MFMA_DENSE=0 disables
 static bool mfma_dense_enabled()
 {
-    const char *e = getenv("CDL_MFMA_DENSE");
-    return !(e && e[0] == '0');
+    return cdl_opts().mfma_dense != 0;
 }
 
 size_t cdl_analysis_workspace_floats(const cdl_geom *g)
 {
-    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
+    if (!cdl_geom_ok(g) || cdl_opts().no_tiled) return 0;
     const size_t a = mfma_analysis_enabled(g) ? cdl_mfma_analysis_ws_floats(g) : 0;
     const size_t b = mfma_dense_enabled() ? cdl_dense_ws_floats(g, 0) : 0;
     return a > b ? a : b;
@@ -630,7 +626,7 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
     if (!cdl_geom_ok(g) || !x || !w || !out) return CDL_EINVAL;
     if (out == zin) return CDL_EINVAL;
     if (gate && !zin) return CDL_EINVAL;
-    if (!getenv("CDL_NO_TILED")) {
+    if (!cdl_opts().no_tiled) {
         if (!px.zp && mfma_dense_enabled()) {
             const int rcd = cdl_dense_conv(g, 0, x, nullptr, w, alpha, zin, gate, nullptr, nullptr, tau, 0, nullptr, out, ws,
                                            ws_floats, stream);
@@ -663,13 +659,12 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
 // selects the fp32 VALU kernels (read per call, so one process can compare both)
 static bool mfma_synthesis_enabled()
 {
-    const char *e = getenv("CDL_MFMA_SYNTHESIS");
-    return !(e && e[0] == '0');
+    return cdl_opts().mfma_synthesis != 0;
 }
 
 size_t cdl_synthesis_workspace_floats(const cdl_geom *g)
 {
-    if (!cdl_geom_ok(g) || getenv("CDL_NO_TILED")) return 0;
+    if (!cdl_geom_ok(g) || cdl_opts().no_tiled) return 0;
     const size_t a = cdl_tiled_synthesis_ws_floats(g);
     size_t b = mfma_synthesis_enabled() ? cdl_mfma_synthesis_ws_floats(g) : 0;
     const size_t d = mfma_dense_enabled() ? cdl_dense_ws_floats(g, 1) : 0;
@@ -688,7 +683,7 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
                      size_t workspace_floats, void *stream)
 {
     if (!cdl_geom_ok(g) || !z || !w || !out) return CDL_EINVAL;
-    if (!getenv("CDL_NO_TILED")) {
+    if (!cdl_opts().no_tiled) {
         if (mfma_dense_enabled()) {
             const int rcd = cdl_dense_conv(g, 1, z, gate, w, alpha, nullptr, nullptr, mask, sub, nullptr, 0, nullptr, out,
                                            workspace, workspace_floats, stream);
@@ -724,8 +719,7 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
 // matrix-core filter gradients are the default wherever they have a kernel; CDL_MFMA_WGRAD=0 selects the VALU ones
 static bool mfma_wgrad_enabled()
 {
-    const char *e = getenv("CDL_MFMA_WGRAD");
-    return !(e && e[0] == '0');
+    return cdl_opts().mfma_wgrad != 0;
 }
 
 size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
@@ -749,7 +743,7 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
 {
     if (!cdl_geom_ok(g) || !z || !x || !dw) return CDL_EINVAL;
     if (g->Pw > PWMAX) return CDL_EUNSUPPORTED;
-    if (!getenv("CDL_NO_TILED")) {
+    if (!cdl_opts().no_tiled) {
         if (mfma_dense_enabled()) {
             const int rcd = cdl_dense_wgrad(g, z, gate, x, alpha, dw, workspace, workspace_floats, stream);
             if (rcd != CDL_EUNSUPPORTED) return rcd;

@@ -789,7 +789,7 @@ int launch_synthesis(const cdl_geom *g, const float *z, const float *gate, const
         // M=169 stride-2 shape 1.02 -> 1.89 ms (4x the rounds and barriers of the 8-channel kernel for little
         // work per round): pipelined only where a round carries Pd or C times more work
         if ((g->Pd > 1 || g->C > 1) && MQ * PZH * PZW <= QNE * 256 && MQ * slab < ((size_t)1 << 31) &&
-            !getenv("CDL_NO_PIPELINED_SYNTHESIS")) {
+            !cdl_opts().no_pipelined_synthesis) {
             const int tilesX = (g->W + TX - 1) / TX, tilesY = (g->H + TY - 1) / TY;
             const size_t lds = (size_t)MQ * PZH * PZW * sizeof(float);
             int chunks;

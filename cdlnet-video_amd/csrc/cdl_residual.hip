@@ -86,8 +86,7 @@ int cdl_residual_forward(const cdl_geom *g, const float *x, const float *w1, con
     if (scratch_floats < cdl_residual_scratch_floats(g) || (scratch_floats && !scratch)) return CDL_EINVAL;
     const size_t n = (size_t)g->N * g->M * g->D * g->H * g->W;
     // dense matrix-core tier: the relu is the convolution's epilogue (2 launches + 2 fragment preps per block)
-    const char *e = getenv("CDL_MFMA_DENSE");
-    if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED")) {
+    if (cdl_opts().mfma_dense && !cdl_opts().no_tiled) {
         const int rc = cdl_dense_conv(g, 0, x, nullptr, w1, 1.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, h,
                                       scratch, scratch_floats, stream);
         if (rc == 0)
@@ -112,8 +111,7 @@ int cdl_residual_backward(const cdl_geom *g, const float *x, const float *h, con
     {   // dense tier: each relu gate is applied ONCE, where the gated gradient is produced (g2 by one element-wise
         // pass into dx, which is free until the last launch; g1 by the epilogue of the launch that computes dh), so
         // the two data-gradient and two filter-gradient launches read no gate (each re-reads its input ~3x)
-        const char *e = getenv("CDL_MFMA_DENSE");
-        if (!(e && e[0] == '0') && !getenv("CDL_NO_TILED") && cdl_dense_ws_floats(g, 1) && cdl_dense_wgrad_ws_floats(g)) {
+        if (cdl_opts().mfma_dense && !cdl_opts().no_tiled && cdl_dense_ws_floats(g, 1) && cdl_dense_wgrad_ws_floats(g)) {
             float *g2 = dx;
             k_gate<<<(unsigned)((n + 255) / 256), 256, 0, S(stream)>>>(g2, g_out, out, n);
             CDL_LAUNCH_CHECK();

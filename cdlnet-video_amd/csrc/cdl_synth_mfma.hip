@@ -289,16 +289,8 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
     const int nprep = g->C * g->Pd * p.RT * p.KS * 64;
     k_synth_prep<<<(nprep + 255) / 256, 256, 0, st>>>(w, frags, g->M, g->C, g->Pd, g->Ph * g->Pw, p.RT, p.KS);
     CDL_LAUNCH_CHECK();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW, 0>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_synth_m<PH, PW, SW, 4>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_synth_m<PH, PW, SW, 0>, 150 * 1024)) return rc;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_synth_m<PH, PW, SW, 4>, 150 * 1024)) return rc;
     if (p.KS <= 4 && g->C * g->Pd > 1)       // several groups share the code values: keep their fragments in registers
         k_synth_m<PH, PW, SW, 4><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH);
     else

@@ -251,13 +251,7 @@ template <int PH, int PW, int SW, int NG>
 int launch_ng(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
               hipStream_t st)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_wgm<PH, PW, SW, NG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG>, 96 * 1024)) return rc;
     k_wgm<PH, PW, SW, NG><<<(unsigned)p.tiles, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP);
     CDL_LAUNCH_CHECK();
     return 0;

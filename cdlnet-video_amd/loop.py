@@ -23,6 +23,10 @@ from . import ops
 # PRECISION applies to the fused kernels only: "split3" (fp32-grade, default) or "bf16".
 BACKEND = "auto"
 PRECISION = "split3"
+# How the fused sweeps store the codes that never leave them (z_1..z_{K-1}, du_k): "blocked" (pixel-blocked
+# fp32: same values as "nchw", wider memory accesses; the default), "nchw", or "blocked_bf16" (opt-in bf16
+# STORAGE: half the bytes of the dominant tensors, outside the 1e-5 parity gate -- PSNR parity only).
+CODE_LAYOUT = "blocked"
 
 
 def set_backend(name):
@@ -37,6 +41,13 @@ def set_precision(name):
     if name not in ops.PRECISION:
         raise ValueError(name)
     PRECISION = name
+
+
+def set_code_layout(name):
+    global CODE_LAYOUT
+    if name not in ops.LAYOUT:
+        raise ValueError(name)
+    CODE_LAYOUT = name
 
 
 def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
@@ -63,15 +74,17 @@ def _forward_generic_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     return xp, z, codes, resid, []
 
 
-def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+def _forward_fused(g, yp, mask_p, tau, A, B, keep_codes, keep_resid, layout=None):
     """The whole sweep from one C call (cdl_fused2d_forward): per iteration one fused launch + a thin
-    assemble, enqueued back to back with no per-launch host work."""
+    assemble, enqueued back to back with no per-launch host work.  codes[:-1] come back in `layout`
+    (default CODE_LAYOUT), codes[-1] = z_K as (N,M,H,W)."""
     keep = keep_codes or keep_resid
-    xp, z, codes, resid, maps = ops.fused_forward(g, yp, mask_p, tau, A, B, keep, PRECISION)
+    xp, z, codes, resid, maps = ops.fused_forward(g, yp, mask_p, tau, A, B, keep, PRECISION,
+                                                  layout or CODE_LAYOUT)
     return xp, z, codes, (resid if keep_resid else []), (maps if keep_resid else [])
 
 
-def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid, layout="nchw"):
     """Same sweep driven launch by launch from Python (kept for tests and experiments)."""
     K = len(A)
     frags = [ops.fused_prep(A[k], B[(k + 1) % K]) for k in range(K)]   # last one pairs A_{K-1} with D = B_0
@@ -80,7 +93,8 @@ def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     r, z = yp, None
     for k in range(K):
         bits = ops.fused_map(g, yp.device) if keep_resid else None
-        z = ops.fused_iter(g, r, z, tau[k], frags[k], 1.0 if k == 0 else -1.0, patches, PRECISION, map_out=bits)
+        z = ops.fused_iter(g, r, z, tau[k], frags[k], 1.0 if k == 0 else -1.0, patches, PRECISION, map_out=bits,
+                           lay_in=layout, lay_out="nchw" if k == K - 1 else layout)
         if keep_codes or k == 0:
             codes.append(z)
         if keep_resid:
@@ -91,6 +105,23 @@ def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
                 resid.append(r)
     xp = ops.fused_assemble(g, patches, None, None, 1.0)
     return xp, z, codes, resid, maps
+
+
+def _forward_fusedg(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
+    """cdl_fusedg_forward: the fused iteration for C > 1 / 3-D / P in {3,5,7} / M <= 64 (one fused launch + a thin
+    assemble per iteration)."""
+    keep = keep_codes or keep_resid
+    xp, z, codes, resid, maps = ops.fusedg_forward(g, yp, mask_p, tau, A, B, keep)
+    return xp, z, codes, (resid if keep_resid else []), (maps if keep_resid else [])
+
+
+def _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+    """cdl_fusedg_backward: per iteration one fused reverse stage (du_k, threshold partials, patches of q_k), a thin
+    assemble and the two filter gradients."""
+    if g_xp is None and g_z is None:
+        return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
+    return ops.fusedg_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
+                               maps=list(maps) if maps else None)
 
 
 def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
@@ -122,16 +153,19 @@ def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_
     return dA, dB
 
 
-def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout=None):
     """Reverse sweep from one C call (cdl_fused2d_backward): per iteration one stage launch (1 fat read +
     the 2-bit map of z_{k+1}, 1 fat write), a thin assemble, and one MFMA filter-gradient launch (2 fat
-    reads).  maps: the forward's bit maps (rebuilt from the codes when absent)."""
+    reads).  maps: the forward's bit maps (rebuilt from the codes when absent); `layout`: that of codes[:-1]."""
+    if g_xp is None and g_z is None:
+        return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
     return ops.fused_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
-                              PRECISION, maps=list(maps) if maps else None)
+                              PRECISION, maps=list(maps) if maps else None, layout=layout or CODE_LAYOUT)
 
 
-def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout="nchw"):
     """Same reverse sweep driven launch by launch from Python (kept for tests and experiments)."""
+    assert maps or layout == "nchw"
     prec = PRECISION
     dev = yp.device
     dA, dB = [None] * K, [None] * K
@@ -142,14 +176,15 @@ def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z,
     (dB[0],) = ops.fused_wgrad(g, ws, codes[K - 1], g_xp, 1.0, precision=prec)[:1]
     for k in range(K - 1, -1, -1):
         frags = ops.fused_prep(B[(k + 1) % K], A[k])          # analysis-like bank, synthesis-like bank
-        du = ops.fused_stage_bwd(g, thin, du_next, maps[k] if maps else codes[k], frags, patches, dtp, k >= 1, prec)
+        du = ops.fused_stage_bwd(g, thin, du_next, maps[k] if maps else codes[k], frags, patches, dtp, k >= 1, prec,
+                                 lay_in="nchw" if k == K - 1 else layout, lay_out=layout)
         ops.fused_dtau_reduce(g, dtp, c, dt[k])
         if k >= 1:
             q = ops.fused_assemble(g, patches, mask_p, None, -1.0)
-            dA[k], dB[k] = ops.fused_wgrad(g, ws, du, resid[k - 1], -1.0, codes[k - 1], q, 1.0, prec)
+            dA[k], dB[k] = ops.fused_wgrad(g, ws, du, resid[k - 1], -1.0, codes[k - 1], q, 1.0, prec, layout=layout)
             thin = q
         else:
-            (dA[0],) = ops.fused_wgrad(g, ws, du, yp, 1.0, precision=prec)[:1]
+            (dA[0],) = ops.fused_wgrad(g, ws, du, yp, 1.0, precision=prec, layout=layout)[:1]
         du_next = du
     return dA, dB
 
@@ -174,8 +209,15 @@ class UnrolledISTA(torch.autograd.Function):
         keep = any(ctx.needs_input_grad)          # all False under torch.no_grad()
         want_codes = cfg.get("all_codes", False)
         ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
-        sweep = _forward_fused if ctx.fused else _forward_generic
-        xp, z, codes, resid, maps = sweep(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
+        ctx.fusedg = BACKEND == "auto" and not ctx.fused and ops.fusedg_supported(g)
+        if ctx.fusedg:
+            xp, z, codes, resid, maps = _forward_fusedg(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
+        elif ctx.fused:
+            # codes handed to the caller (forward_generator) must be (N,M,H,W); otherwise they stay internal
+            ctx.layout = "nchw" if want_codes else CODE_LAYOUT
+            xp, z, codes, resid, maps = _forward_fused(g, yp, mask_p, tau, A, B, keep or want_codes, keep, ctx.layout)
+        else:
+            xp, z, codes, resid, maps = _forward_generic(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
         xhat = ops.postprocess(xp, mean, pads)
 
         ctx.geom, ctx.pads, ctx.K = g, pads, K
@@ -209,8 +251,13 @@ class UnrolledISTA(torch.autograd.Function):
         g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads) if g_xhat is not None else None
         if g_z is not None:
             g_z = g_z.contiguous()
-        sweep = _backward_fused if (ctx.fused and g_xp is not None) else _backward_generic
-        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
+        if ctx.fusedg:
+            dA, dB = _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
+        elif ctx.fused:                                # a loss on z only is a zero image gradient to the sweep
+            dA, dB = _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps,
+                                     layout=ctx.layout)
+        else:
+            dA, dB = _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
 
         return (None, None, None, dt.reshape(t.shape), None, *dA, *dB)
 
@@ -361,7 +408,8 @@ class ResidualBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2):
         g = ops.residual_geometry(x, w1)
-        h, out = ops.residual_forward(g, x.contiguous(), w1, w2)
+        x = x.contiguous()                    # what the kernels read is what backward must see
+        h, out = ops.residual_forward(g, x, w1, w2)
         ctx.g = g
         ctx.save_for_backward(x, h, out, w1, w2)
         return out

@@ -13,7 +13,36 @@ from . import _lib
 
 
 def _stream():
+    """Stream of the CURRENT device: every public function of this module runs under `_on_tensor_device`,
+    which makes the tensors' device current first, so this is the tensors' stream."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_tensor(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if torch.is_tensor(a) and a.is_cuda:
+            return a
+        if isinstance(a, (list, tuple)):
+            for b in a:
+                if torch.is_tensor(b) and b.is_cuda:
+                    return b
+    return None
+
+
+def _on_tensor_device(fn):
+    """Run `fn` with its first CUDA tensor argument's device current (net.to('cuda:1') without a
+    torch.cuda.set_device(1) must not hand cuda:1 pointers to a stream of cuda:0).  `_dev` then rejects
+    any further tensor that lives elsewhere."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = _first_cuda_tensor(args, kwargs)
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -29,6 +58,9 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
             "(libcdlnet_hip.so) on a ROCm device; move the module and inputs to 'cuda'.")
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{name} is on {t.device} but this call runs on cuda:{torch.cuda.current_device()}: "
+                           "all tensors of one call must live on one device")
     return t.contiguous()
 
 
@@ -347,9 +379,11 @@ def residual_forward(g: Geometry, x, w1, w2):
 
 def residual_backward(g: Geometry, x, h, out, w1, w2, g_out):
     """(dx, dw1, dw2) for g_out = dL/dout."""
-    g_out = _dev(g_out, "g_out")
-    dx, dh = torch.empty_like(x), torch.empty_like(x)
-    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    x, h, out = _dev(x, "x"), _dev(h, "h"), _dev(out, "out")
+    w1, w2, g_out = _dev(w1, "w1"), _dev(w2, "w2"), _dev(g_out, "g_out")
+    new = lambda t: torch.empty(t.shape, device=t.device, dtype=torch.float32)      # contiguous, whatever t's strides
+    dx, dh = new(x), new(x)
+    dw1, dw2 = new(w1), new(w2)
     gs = g.c_struct()
     n = int(_lib.lib().cdl_residual_scratch_floats(ctypes.byref(gs)))
     ws = _scratch(x.device, n) if n else None
@@ -410,6 +444,52 @@ def gabor_filters_bwd(alpha, a, w0, psi, dw, P, transpose):
 
 # ------------------------------------------------------------------------------------------ fused MFMA path
 PRECISION = {"split3": 0, "bf16": 1}
+# layouts of the fat tensors that stay inside a fused sweep (include/cdlnet_hip.h, CDL_LAY_*): "nchw" is the
+# reference's layout, "blocked" the pixel-blocked fp32 layout (same values, 16-byte accesses, the default),
+# "blocked_bf16" opt-in bf16 STORAGE of the codes (half the bytes; outside the 1e-5 parity gate)
+LAYOUT = {"nchw": 0, "blocked": 1, "blocked_bf16": 2}
+TILES_REVERSED = 16
+
+
+def _lay_in(layout):
+    return LAYOUT[layout] << 5
+
+
+def _lay_out(layout):
+    return LAYOUT[layout] << 7
+
+
+def fused_code_buffer(g: "Geometry", layout, device, count=1):
+    """`count` code tensors in `layout`: NCHW tensors for "nchw", flat byte-sized fp32 / bf16 buffers otherwise."""
+    if layout == "nchw":
+        return torch.empty((count,) + g.code_shape(), device=device, dtype=torch.float32)
+    gs = g.c_struct()
+    nbytes = int(_lib.lib().cdl_fused2d_code_bytes(ctypes.byref(gs), LAYOUT[layout]))
+    assert nbytes > 0
+    if layout == "blocked":
+        return torch.empty((count, nbytes // 4), device=device, dtype=torch.float32)
+    return torch.empty((count, nbytes // 2), device=device, dtype=torch.bfloat16)
+
+
+def fused_to_nchw(g: "Geometry", t, layout):
+    """A blocked code tensor as (N, M, H, W) fp32 (host-side plumbing for tests and tools: a torch permute)."""
+    if layout == "nchw":
+        return t
+    H, W = g.dims[1], g.dims[2]
+    XB = (W + 31) // 32
+    v = t.reshape(g.N, H, XB, g.M // 4, 32, 4).to(torch.float32)
+    return v.permute(0, 3, 5, 1, 2, 4).reshape(g.N, g.M, H, XB * 32)[..., :W].contiguous()
+
+
+def fused_from_nchw(g: "Geometry", z, layout):
+    """Inverse of fused_to_nchw (padding pixels are zero)."""
+    if layout == "nchw":
+        return z
+    H, W = g.dims[1], g.dims[2]
+    XB = (W + 31) // 32
+    zp = torch.nn.functional.pad(z, (0, XB * 32 - W))
+    v = zp.reshape(g.N, g.M // 4, 4, H, XB, 32).permute(0, 3, 4, 1, 5, 2).contiguous().reshape(1, -1)
+    return v[0].to(torch.bfloat16 if layout == "blocked_bf16" else torch.float32)
 
 
 def fused_supported(g: Geometry) -> bool:
@@ -456,15 +536,19 @@ def fused_support_map(g: Geometry, z, out=None):
     return out
 
 
-def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3", out=None, map_out=None):
-    r, zin, tau = _dev(r, "r"), _opt(zin, "zin"), _dev(tau, "tau")
+def fused_iter(g: Geometry, r, zin, tau, frags, sgn, patches, precision="split3", out=None, map_out=None,
+               lay_in="nchw", lay_out="nchw"):
+    """One fused iteration.  lay_in / lay_out: layouts of zin / the result (a flat buffer unless "nchw")."""
+    r, tau = _dev(r, "r"), _dev(tau, "tau")
+    if zin is not None and lay_in == "nchw":
+        zin = _dev(zin, "zin")
     assert tuple(r.shape) == g.image_shape()
     if out is None:
-        out = torch.empty(g.code_shape(), device=r.device, dtype=torch.float32)
+        out = fused_code_buffer(g, lay_out, r.device)[0]
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_iter_fwd(ctypes.byref(gs), _ptr(r), _ptr(zin), _ptr(tau), _ptr(frags),
                                          float(sgn), _ptr(out), _ptr(patches), _ptr(map_out),
-                                         PRECISION[precision], _stream())
+                                         PRECISION[precision] | _lay_in(lay_in) | _lay_out(lay_out), _stream())
     _lib.check(rc, "cdl_fused2d_iter_fwd")
     return out
 
@@ -487,19 +571,22 @@ def fused_tiles(g: Geometry) -> int:
 
 
 def fused_stage_bwd(g: Geometry, thin, base, gate, frags, patches, dtau_partial, do_synth,
-                    precision="split3", out=None):
+                    precision="split3", out=None, lay_in="nchw", lay_out="nchw"):
     """One reverse-sweep stage: du = [z' != 0] * (base + corr(thin; W1)); patches = W2^T du.  `gate` is the
     bit map of z' (int32, from the forward or fused_support_map) or z' itself (the map is built first)."""
-    thin, base = _dev(thin, "thin"), _opt(base, "base")
+    thin = _dev(thin, "thin")
+    if base is not None and lay_in == "nchw":
+        base = _dev(base, "base")
     if gate.dtype != torch.int32:
         gate = fused_support_map(g, gate)
     assert gate.is_cuda and gate.is_contiguous() and gate.numel() == g.N * 4 * g.dims[1] * g.dims[2]
     if out is None:
-        out = torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32)
+        out = fused_code_buffer(g, lay_out, thin.device)[0]
     gs = g.c_struct()
     rc = _lib.lib().cdl_fused2d_stage_bwd(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate),
                                           _ptr(frags), _ptr(out), _ptr(patches), _ptr(dtau_partial),
-                                          int(bool(do_synth)), PRECISION[precision], _stream())
+                                          int(bool(do_synth)),
+                                          PRECISION[precision] | _lay_in(lay_in) | _lay_out(lay_out), _stream())
     _lib.check(rc, "cdl_fused2d_stage_bwd")
     return out
 
@@ -521,8 +608,8 @@ def fused_wgrad_workspace(g: Geometry, device):
 
 
 def fused_wgrad(g: Geometry, workspace, X0=None, T0=None, alpha0=1.0, X1=None, T1=None, alpha1=1.0,
-                precision="split3"):
-    """Up to two filter gradients in one launch: dw_a = alpha_a * sum X_a (x) im2col(T_a)."""
+                precision="split3", layout="nchw"):
+    """Up to two filter gradients in one launch: dw_a = alpha_a * sum X_a (x) im2col(T_a); `layout` of X0, X1."""
     outs = []
     args = []
     for X, T, al in ((X0, T0, alpha0), (X1, T1, alpha1)):
@@ -530,13 +617,13 @@ def fused_wgrad(g: Geometry, workspace, X0=None, T0=None, alpha0=1.0, X1=None, T
             outs.append(None)
             args += [None, None, 0.0, None]
         else:
-            X, T = _dev(X, "X"), _dev(T, "T")
+            X, T = (_dev(X, "X") if layout == "nchw" else X), _dev(T, "T")
             dw = torch.empty(g.filter_shape(), device=X.device, dtype=torch.float32)
             outs.append(dw)
             args += [_ptr(X), _ptr(T), float(al), _ptr(dw)]
     gs = g.c_struct()
-    rc = _lib.lib().cdl_fused2d_wgrad(ctypes.byref(gs), *args, _ptr(workspace), PRECISION[precision],
-                                      _stream())
+    rc = _lib.lib().cdl_fused2d_wgrad(ctypes.byref(gs), *args, _ptr(workspace),
+                                      PRECISION[precision] | _lay_in(layout), _stream())
     _lib.check(rc, "cdl_fused2d_wgrad")
     return outs
 
@@ -546,22 +633,24 @@ def _ptr_table(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
+def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3", layout="blocked"):
     """Whole forward sweep in one C call.  keep=True: every z_k and r_k gets its own buffer (training) and
     each launch also writes the support/sign bit map of its z_{k+1}; keep=False: two ping-pong buffers
-    each, no maps.  Returns (xp, z_K, codes, resid, maps)."""
+    each, no maps.  `layout`: how z_1..z_{K-1} are stored (they never leave the sweeps; z_K is always NCHW).
+    Returns (xp, z_K, codes, resid, maps); codes[:-1] are flat buffers in `layout` unless it is "nchw"."""
     K = len(A)
     yp, tau = _dev(yp, "yp"), _dev(tau, "tau")
     mask_p = _opt(mask_p, "mask")
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
     dev = yp.device
-    nz = K if keep else min(K, 2)
+    nz = (K - 1) if keep else min(K - 1, 2)              # inner codes z_1..z_{K-1}
     nr = (K - 1) if keep else min(K - 1, 2)
-    # one allocation per family (K views into it): at cfg1's size the allocator calls cost more than the kernels
-    zbuf = torch.empty((nz,) + g.code_shape(), device=dev, dtype=torch.float32)
+    # one allocation per family (views into it): at cfg1's size the allocator calls cost more than the kernels
+    zK = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
+    zbuf = fused_code_buffer(g, layout, dev, max(nz, 1))
     rbuf = torch.empty((max(nr, 1),) + g.image_shape(), device=dev, dtype=torch.float32)
-    z = [zbuf[k % nz] for k in range(K)]
+    z = [zbuf[k % nz] for k in range(K - 1)] + [zK]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
     maps = list(torch.empty((K, g.N, 4, g.dims[1], g.dims[2]), device=dev, dtype=torch.int32).unbind(0)) if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
@@ -571,27 +660,32 @@ def fused_forward(g: Geometry, yp, mask_p, tau, A, B, keep, precision="split3"):
     rc = _lib.lib().cdl_fused2d_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
                                         _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None,
                                         _ptr_table(maps) if maps else None, _ptr(xp), _ptr(frags), _ptr(patches),
-                                        PRECISION[precision], _stream())
+                                        PRECISION[precision] | _lay_in(layout), _stream())
     _lib.check(rc, "cdl_fused2d_forward")
     return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else []), maps
 
 
-def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, precision="split3", maps=None):
+def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, precision="split3", maps=None,
+                   layout="blocked"):
     """Whole reverse sweep in one C call; returns (dA list, dB list); dt (K,2,M) is written in place.
-    maps: the forward's bit maps of z_1..z_K (built here from the codes when not given)."""
+    maps: the forward's bit maps of z_1..z_K (built here from the codes when not given).  `layout`: that of
+    codes[:-1] (as fused_forward returned them) and of the du work buffers; codes[-1] = z_K, g_z: NCHW.
+    g_xp None (a loss on the code only) is a zero image gradient."""
     K = len(A)
     dev = yp.device
     if not maps:
-        maps = [fused_support_map(g, t) for t in codes]
+        maps = [fused_support_map(g, fused_to_nchw(g, t, layout if k < K - 1 else "nchw")) for k, t in enumerate(codes)]
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
-    codes = [_dev(t, "z") for t in codes]
+    codes = [(_dev(t, "z") if (layout == "nchw" or k == K - 1) else t) for k, t in enumerate(codes)]
     resid = [_dev(t, "r") for t in resid]
+    if g_xp is None:
+        g_xp = torch.zeros(g.image_shape(), device=dev, dtype=torch.float32)
     g_xp, g_z, c, mask_p = _dev(g_xp, "g_xp"), _opt(g_z, "g_z"), _opt(c, "c"), _opt(mask_p, "mask")
     dAB = torch.empty((2 * K,) + g.filter_shape(), device=dev, dtype=torch.float32)     # one allocation, 2K views
     dA, dB = list(dAB[:K].unbind(0)), list(dAB[K:].unbind(0))
-    du0 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
-    du1 = torch.empty(g.code_shape(), device=dev, dtype=torch.float32) if K > 1 else du0
+    dub = fused_code_buffer(g, layout, dev, 2 if K > 1 else 1)
+    du0, du1 = dub[0], dub[1 if K > 1 else 0]
     q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
     frags = torch.empty(K * _lib.lib().cdl_fused2d_frag_bytes(g.M), device=dev, dtype=torch.uint8)
     patches = fused_patches(g, dev)
@@ -603,9 +697,164 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
         ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(c), _ptr_table(A), _ptr_table(B), _ptr_table(codes),
         _ptr_table(resid) if resid else None, _ptr_table(list(maps)), _ptr(g_xp), _ptr(g_z), _ptr_table(dA),
         _ptr_table(dB), _ptr(dt),
-        _ptr(du0), _ptr(du1), _ptr(q), _ptr(frags), _ptr(patches), _ptr(dtp), _ptr(ws), PRECISION[precision],
-        _stream())
+        _ptr(du0), _ptr(du1), _ptr(q), _ptr(frags), _ptr(patches), _ptr(dtp), _ptr(ws),
+        PRECISION[precision] | _lay_in(layout), _stream())
     _lib.check(rc, "cdl_fused2d_backward")
+    return dA, dB
+
+
+# ------------------------------------------------------------------------------------------ fused generic path
+# cdl_fusedg.hip: the fused iteration for any C, 2-D / 3-D, unit stride, P in {3,5,7}, M <= 64 (BASELINE configs[2]
+# and [3]); same call structure as the 2-D flagship path above, codes in the reference's (N,M,[D,]H,W) layout.
+def fusedg_supported(g: Geometry) -> bool:
+    gs = g.c_struct()
+    return bool(_lib.lib().cdl_fusedg_supported(ctypes.byref(gs)))
+
+
+def _fusedg_sizes(g: Geometry):
+    gs = g.c_struct()
+    L = _lib.lib()
+    return (int(L.cdl_fusedg_frag_bytes(ctypes.byref(gs))), int(L.cdl_fusedg_patch_floats(ctypes.byref(gs))),
+            int(L.cdl_fusedg_tiles(ctypes.byref(gs))), int(L.cdl_fusedg_map_words(ctypes.byref(gs))))
+
+
+def fusedg_map(g: Geometry, device):
+    return torch.empty((g.N, 4) + tuple(g.dims), device=device, dtype=torch.int32)
+
+
+def fusedg_prep(g: Geometry, wA, wB):
+    wA, wB = _dev(wA, "wA"), _dev(wB, "wB")
+    frags = torch.empty(_fusedg_sizes(g)[0], device=wA.device, dtype=torch.uint8)
+    gs = g.c_struct()
+    _lib.check(_lib.lib().cdl_fusedg_prep(ctypes.byref(gs), _ptr(wA), _ptr(wB), _ptr(frags), _stream()), "cdl_fusedg_prep")
+    return frags
+
+
+def fusedg_patches(g: Geometry, device):
+    return torch.empty(_fusedg_sizes(g)[1], device=device, dtype=torch.float32)
+
+
+def fusedg_iter(g: Geometry, r, zin, tau, frags, sgn, patches, out=None, map_out=None):
+    r, zin, tau = _dev(r, "r"), _opt(zin, "zin"), _dev(tau, "tau")
+    assert tuple(r.shape) == g.image_shape()
+    if out is None:
+        out = torch.empty(g.code_shape(), device=r.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fusedg_iter_fwd(ctypes.byref(gs), _ptr(r), _ptr(zin), _ptr(tau), _ptr(frags), float(sgn),
+                                        _ptr(out), _ptr(patches), _ptr(map_out), 0, _stream())
+    _lib.check(rc, "cdl_fusedg_iter_fwd")
+    return out
+
+
+def fusedg_assemble(g: Geometry, patches, mask=None, sub=None, alpha=1.0, out=None):
+    mask, sub = _opt(mask, "mask"), _opt(sub, "sub")
+    if out is None:
+        out = torch.empty(g.image_shape(), device=patches.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fusedg_assemble(ctypes.byref(gs), _ptr(patches), _ptr(mask), _ptr(sub), float(alpha),
+                                        _ptr(out), _stream())
+    _lib.check(rc, "cdl_fusedg_assemble")
+    return out
+
+
+def fusedg_support_map(g: Geometry, z):
+    """Bit map of a code tensor in the layout the fused stages use: (N, 4, D, H, W) words, plane 2h = [z != 0], plane
+    2h + 1 = sign bit, bit 16R + v = channel 32R + 8(v>>2) + 4h + (v&3) (host-side plumbing for tests)."""
+    z = _dev(z, "z")
+    N, M = z.shape[:2]
+    sp = tuple(g.dims)
+    zz = z.reshape((N, M) + sp)
+    out = torch.zeros((N, 4) + sp, device=z.device, dtype=torch.int64)
+    for ch in range(M):
+        R, rem = divmod(ch, 32)
+        q, rem = divmod(rem, 8)
+        h, e = divmod(rem, 4)
+        bit = 16 * R + 4 * q + e
+        out[:, 2 * h] |= (zz[:, ch] != 0).to(torch.int64) << bit
+        out[:, 2 * h + 1] |= (torch.signbit(zz[:, ch])).to(torch.int64) << bit
+    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
+    return out.to(torch.int32).contiguous()
+
+
+def fusedg_stage_bwd(g: Geometry, thin, base, gate_map, frags, patches, dtau_partial, do_synth, out=None):
+    thin, base = _dev(thin, "thin"), _opt(base, "base")
+    assert gate_map.dtype == torch.int32 and gate_map.is_contiguous()
+    if out is None:
+        out = torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fusedg_stage_bwd(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate_map), _ptr(frags),
+                                         _ptr(out), _ptr(patches), _ptr(dtau_partial), int(bool(do_synth)), 0, _stream())
+    _lib.check(rc, "cdl_fusedg_stage_bwd")
+    return out
+
+
+def fusedg_dtau_reduce(g: Geometry, dtau_partial, c, dt_k):
+    assert dt_k.is_contiguous() and dt_k.numel() == 2 * g.M
+    gs = g.c_struct()
+    base = dt_k.data_ptr()
+    rc = _lib.lib().cdl_fusedg_dtau_reduce(ctypes.byref(gs), _ptr(dtau_partial), _ptr(_opt(c, "c")),
+                                           ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * g.M), _stream())
+    _lib.check(rc, "cdl_fusedg_dtau_reduce")
+
+
+def fusedg_forward(g: Geometry, yp, mask_p, tau, A, B, keep):
+    """Whole forward sweep in one C call (cdl_fusedg_forward); same contract as fused_forward, NCHW codes."""
+    K = len(A)
+    yp, tau, mask_p = _dev(yp, "yp"), _dev(tau, "tau"), _opt(mask_p, "mask")
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    dev = yp.device
+    fb, pf, tiles, mw = _fusedg_sizes(g)
+    nz = K if keep else min(K, 2)
+    nr = (K - 1) if keep else min(K - 1, 2)
+    zbuf = torch.empty((nz,) + g.code_shape(), device=dev, dtype=torch.float32)
+    rbuf = torch.empty((max(nr, 1),) + g.image_shape(), device=dev, dtype=torch.float32)
+    z = [zbuf[k % nz] for k in range(K)]
+    r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
+    maps = list(torch.empty((K, g.N, 4) + tuple(g.dims), device=dev, dtype=torch.int32).unbind(0)) if keep else []
+    xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
+    frags = torch.empty(K * fb, device=dev, dtype=torch.uint8)
+    patches = torch.empty(pf, device=dev, dtype=torch.float32)
+    gs = g.c_struct()
+    rc = _lib.lib().cdl_fusedg_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
+                                       _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None,
+                                       _ptr_table(maps) if maps else None, _ptr(xp), _ptr(frags), _ptr(patches),
+                                       0, _stream())
+    _lib.check(rc, "cdl_fusedg_forward")
+    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else []), maps
+
+
+def fusedg_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+    """Whole reverse sweep in one C call (cdl_fusedg_backward); returns (dA list, dB list), fills dt (K,2,M)."""
+    K = len(A)
+    dev = yp.device
+    if not maps:
+        maps = [fusedg_support_map(g, t) for t in codes]
+    A = [_dev(w, "A") for w in A]
+    B = [_dev(w, "B") for w in B]
+    codes = [_dev(t, "z") for t in codes]
+    resid = [_dev(t, "r") for t in resid]
+    if g_xp is None:
+        g_xp = torch.zeros(g.image_shape(), device=dev, dtype=torch.float32)
+    g_xp, g_z, c, mask_p = _dev(g_xp, "g_xp"), _opt(g_z, "g_z"), _opt(c, "c"), _opt(mask_p, "mask")
+    fb, pf, tiles, mw = _fusedg_sizes(g)
+    dAB = torch.empty((2 * K,) + g.filter_shape(), device=dev, dtype=torch.float32)
+    dA, dB = list(dAB[:K].unbind(0)), list(dAB[K:].unbind(0))
+    du = torch.empty((2 if K > 1 else 1,) + g.code_shape(), device=dev, dtype=torch.float32)
+    q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
+    frags = torch.empty(K * fb, device=dev, dtype=torch.uint8)
+    patches = torch.empty(pf, device=dev, dtype=torch.float32)
+    dtp = torch.empty((tiles, g.M), device=dev, dtype=torch.float32)
+    gs = g.c_struct()
+    nws = int(_lib.lib().cdl_wgrad_workspace_floats(ctypes.byref(gs)))
+    ws = torch.empty(max(nws, 1), device=dev, dtype=torch.float32)
+    assert dt.is_contiguous() and dt.numel() == K * 2 * g.M
+    rc = _lib.lib().cdl_fusedg_backward(
+        ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(c), _ptr_table(A), _ptr_table(B), _ptr_table(codes),
+        _ptr_table(resid) if resid else None, _ptr_table(list(maps)), _ptr(g_xp), _ptr(g_z), _ptr_table(dA),
+        _ptr_table(dB), _ptr(dt), _ptr(du[0]), _ptr(du[1 if K > 1 else 0]), _ptr(q), _ptr(frags), _ptr(patches),
+        _ptr(dtp), _ptr(ws), nws, 0, _stream())
+    _lib.check(rc, "cdl_fusedg_backward")
     return dA, dB
 
 
@@ -686,3 +935,11 @@ def fused_timing_read():
     _lib.check(_lib.lib().cdl_fused2d_timing_read(ms, cnt), "cdl_fused2d_timing_read")
     names = ("stage_fwd", "stage_bwd", "wgrad", "stage_first")
     return {n: ((ms[i] / cnt[i]) if cnt[i] else 0.0, int(cnt[i])) for i, n in enumerate(names)}
+
+
+# every public wrapper runs with its tensors' device current (see _on_tensor_device)
+for _name, _obj in list(globals().items()):
+    if callable(_obj) and not _name.startswith("_") and getattr(_obj, "__module__", None) == __name__ \
+            and not isinstance(_obj, type):
+        globals()[_name] = _on_tensor_device(_obj)
+del _name, _obj

@@ -14,7 +14,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import torch.distributed as dist
+
 from .net import CDLNet, CDLNet_CSR, CDLNet_CSRf2, CDLNetVideo, GDLNet
+from .parallel import phase_consensus
 from .utils import awgn, gen_bayer_mask
 
 MODEL_TYPES = {
@@ -147,7 +150,7 @@ def save_args(args, ckpt=True):
 
 def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), save_dir=None, start_epoch=1,
         clip_grad=1, noise_std=25, demosaic=False, verbose=True, val_freq=1, save_freq=1, epoch_fun=None,
-        mcsure=False, backtrack_thresh=1, grad_sync=None, log=print):
+        mcsure=False, backtrack_thresh=1, grad_sync=None, log=print, group=None):
     """The reference's training driver (train.py:35-158), same arguments and files:
 
     * phases train / val (every `val_freq` epochs) / test (only at `epoch == epochs`, as written there);
@@ -159,10 +162,28 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
     * scheduler step per epoch; `net.ckpt` (+ `epoch_fun(epoch)`) every `save_freq` epochs; `0.ckpt` at start.
 
     `loaders` maps phase -> iterable of clean batches.  `grad_sync` (new) is run after backward for data
-    parallel training (parallel.GradientBucket.sync); every rank then needs its own `save_dir` (or a
-    shared one written by identical ranks) so that backtracking reloads the same weights everywhere.
+    parallel training (parallel.GradientBucket.sync).  Under data parallelism (an initialised process
+    group; `group` selects it) every rank sees a different shard, so the decisions that change the
+    training state are taken on REDUCED values: the phase PSNR is the mean over all ranks' batches and the
+    nan / inf flag is the OR over ranks (parallel.phase_consensus) -- every rank backtracks, or none does.
+    Rank 0 alone writes logs and checkpoints into `save_dir` (one node: the directory is shared); a
+    barrier orders its writes before the other ranks' reads, and a backtrack reloads the SAME file on
+    every rank, so replicas, optimiser states and learning rates stay identical.
     Returns the history [(epoch, phase, psnr)].
     """
+    ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank0 = (not ddp) or dist.get_rank(group) == 0
+    sync_dev = next(net.parameters()).device
+
+    def barrier():
+        if ddp:
+            dist.barrier(group=group)
+
+    def append(name, text):
+        if rank0:
+            with open(os.path.join(save_dir, name), "a") as f:
+                f.write(text)
+
     if save_dir is None:
         raise ValueError("fit needs save_dir (checkpoints drive the backtracking)")
     os.makedirs(save_dir, exist_ok=True)
@@ -170,7 +191,9 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
         noise_std = (noise_std, noise_std)
     log(f"fit: using device {device}")
     log("Saving initialization to 0.ckpt")
-    save_ckpt(os.path.join(save_dir, "0.ckpt"), net, 0, opt, sched)
+    if rank0:
+        save_ckpt(os.path.join(save_dir, "0.ckpt"), net, 0, opt, sched)
+    barrier()
     top_psnr = {"train": 0, "val": 0, "test": 0}
     history = []
     epoch = start_epoch
@@ -185,7 +208,7 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
             if phase not in loaders or loaders[phase] is None:
                 continue
             phase_nstd = noise_std if phase == "train" else (noise_std[0] + noise_std[1]) / 2.0
-            psnr, nb = 0.0, 0
+            psnr, nb, bad = 0.0, 0, False
             for batch in loaders[phase]:
                 batch = batch.to(device)
                 if phase == "train":
@@ -201,22 +224,24 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
                 if verbose and phase == "train":
                     log(f"{phase.upper()}-E{epoch} loss={loss:.1e}|gnorm={grad_norm(net.parameters()):.1e}")
                 psnr = psnr - 10 * np.log10(loss) if loss > 0 else float("nan")
+                bad = bad or bool(np.isnan(loss) or np.isinf(loss))
                 nb += 1
-            psnr = psnr / max(nb, 1)
+            # one reduction per phase: mean PSNR over every rank's batches, nan / inf on ANY rank
+            psnr, bad = phase_consensus(psnr, nb, bad or bool(np.isnan(psnr)), sync_dev, group)
+            if bad:
+                psnr = float("nan")
             log(f"{phase.upper()} PSNR: {psnr:.3f} dB")
             history.append((epoch, phase, psnr))
             if psnr > top_psnr[phase]:
                 top_psnr[phase] = psnr
-            elif (psnr + backtrack_thresh < top_psnr[phase]) or np.isnan(loss) or np.isinf(loss) or np.isnan(psnr):
+            elif (psnr + backtrack_thresh < top_psnr[phase]) or bad:
                 diverged = True
                 break
-            with open(os.path.join(save_dir, f"{phase}.txt"), "a") as f:
-                f.write(f"{psnr:.3f}, ")
+            append(f"{phase}.txt", f"{psnr:.3f}, ")
         if diverged:
             ckpt_path = os.path.join(save_dir, "0.ckpt" if epoch <= save_freq else "net.ckpt")
             log(f"Loss has diverged. Backtracking to {ckpt_path} ...")
-            with open(os.path.join(save_dir, "backtrack.txt"), "a") as f:
-                f.write(f"{epoch}  ")
+            append("backtrack.txt", f"{epoch}  ")
             epoch = epoch - save_freq if epoch % save_freq == 0 else epoch - epoch % save_freq
             old_lr = np.array(getlr(opt))
             load_ckpt(ckpt_path, net, opt, sched)
@@ -228,8 +253,10 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
         if sched is not None:
             sched.step()
         if epoch % save_freq == 0:
-            save_ckpt(os.path.join(save_dir, "net.ckpt"), net, epoch, opt, sched)
-            if epoch_fun is not None:
-                epoch_fun(epoch)
+            if rank0:
+                save_ckpt(os.path.join(save_dir, "net.ckpt"), net, epoch, opt, sched)
+                if epoch_fun is not None:
+                    epoch_fun(epoch)
+            barrier()                            # the file is complete before any rank may reload it
         epoch = epoch + 1
     return history

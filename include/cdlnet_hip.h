@@ -16,8 +16,12 @@
  *       filter bank  (M, C, Pd, Ph, Pw)   -- Conv{2,3}d.weight and ConvTranspose{2,3}d.weight
  *                                            share this shape (net.py:32-33, 137-142)
  *     2-D nets are the D = Pd = sd = 1, pd = 0 special case;
- *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and do not
- *     synchronise; no global state, re-entrant across streams / ranks;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*, of the CURRENT device) and do
+ *     not synchronise.  The compute entry points keep no state between calls and are re-entrant
+ *     across streams, devices and ranks; what is process-wide is lock-protected and off the data
+ *     path: a snapshot of the experiment switches read once from the environment
+ *     (cdl_options_reload), per-device launch attributes, and the opt-in kernel timing of
+ *     cdl_fused2d_timing (bench.py only);
  *   - return 0 on success, a negative value on error: -(hipError_t) for runtime errors,
  *     CDL_EINVAL / CDL_EUNSUPPORTED for argument errors.  Nothing throws.
  *   - in-place is allowed only where a parameter says "inout".
@@ -46,6 +50,10 @@ typedef struct cdl_geom {
 } cdl_geom;
 
 const char *cdl_version(void);
+
+/* Re-read the CDL_* experiment switches from the environment (they are read once, at first use, into an
+ * immutable snapshot; tests and tools that flip a variable mid-process call this afterwards). */
+int cdl_options_reload(void);
 
 /* ---- boundary of the loop: model/utils.py:5-22 (pre_process), :70-87 (pre_process_3d) -------
  * mean[n] = sum(y[n]) / (mask ? sum(mask[n]) : numel);  yp = reflect_pad(mask * (y - mean));
@@ -244,6 +252,23 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
  * are grouped differently (still deterministic).  The whole-sweep entry points alternate it per launch. */
 #define CDL_TILES_REVERSED 16
 
+/* Layouts of the fat (code-like) operands of the fused path, OR-ed into `precision` as well:
+ *   CDL_LAY_NCHW   (N, M, H, W) fp32 -- the reference's layout; what leaves or enters a sweep (z_K, user gradients)
+ *   CDL_LAY_BLK    pixel-blocked fp32 [n][y][ceil(W/32)][M/4][32 px][4 ch]: 16 contiguous bytes per lane and
+ *                  register quad, 8 KiB contiguous per 32-pixel row block (measured 5.65 vs 5.08 TB/s for a pure
+ *                  load -> store stream of the cfg2 code tensor, tools/probes/probe_stream.hip); for tensors that
+ *                  stay INSIDE a sweep (z_1..z_{K-1}, du_k).  Bit-identical values to CDL_LAY_NCHW.
+ *   CDL_LAY_BLK16  the same blocking with bf16 elements: opt-in reduced-precision STORAGE (half the fat bytes;
+ *                  arithmetic and accumulation stay as `precision` says; the 1e-5 parity gate does not apply).
+ * cdl_fused2d_iter_fwd / _stage_bwd: CDL_LAYOUT_IN = zin / base, CDL_LAYOUT_OUT = zout / du_out (pairs: equal
+ * layouts, or NCHW on exactly one side).  cdl_fused2d_wgrad: CDL_LAYOUT_IN = X0 and X1.  cdl_fused2d_forward /
+ * _backward: CDL_LAYOUT_IN = the layout of z[0..K-2] and of the du ping-pong buffers (z[K-1], g_z: NCHW). */
+#define CDL_LAY_NCHW  0
+#define CDL_LAY_BLK   1
+#define CDL_LAY_BLK16 2
+#define CDL_LAYOUT_IN(l)  ((l) << 5)
+#define CDL_LAYOUT_OUT(l) ((l) << 7)
+
 /* ==== fused MFMA path (cdl_fused2d.hip): 2-D, C = 1, stride 1, odd P <= 7, M in {32, 64} =========
  * One launch per unrolled iteration replaces the whole body of net.py:87
  *     z = ST(z - A_k(mask*B_k(z) - yp), tau_k)
@@ -257,6 +282,7 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
 int cdl_fused2d_supported(const cdl_geom *g);              /* 1 if this geometry has a fused kernel */
 size_t cdl_fused2d_frag_bytes(int M);                      /* bytes of one prepared (A_k, B_next) pair */
 size_t cdl_fused2d_patch_floats(const cdl_geom *g);        /* floats in the patch workspace */
+size_t cdl_fused2d_code_bytes(const cdl_geom *g, int layout);   /* bytes of one code tensor in CDL_LAY_* */
 /* fp32 filters (M,1,P,P) -> bf16 hi/lo MFMA operand fragments for one launch (A_k with B_next). */
 int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P, void *stream);
 /* map_out (nullable, cdl_fused2d_map_words(g) words): support / sign bit planes of z_{k+1} for the reverse
@@ -318,6 +344,42 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
                          float *dt,
                          float *du0, float *du1, float *q, void *frags, float *patches,
                          float *dtau_partial, float *wgrad_ws, int precision, void *stream);
+
+/* ==== fused MFMA path for the other shapes (cdl_fusedg.hip): any C, 2-D / 3-D, unit stride, square planes ====
+ * P in {3,5,7}, odd Pd with C*Pd in {1,3,5,7}, M <= 64 -- CDLNetVideo.forward's loop body (net.py:204-207) and
+ * CDLNet.forward's (net.py:86-87) with C = 3 + mask (JDD).  Same fusion boundary and call structure as the
+ * cdl_fused2d_* family above: one launch per iteration takes (r_k thin, z_k fat) to (z_{k+1} fat, patches of
+ * B_next z_{k+1}); cdl_fusedg_assemble sums the patches over tiles and depth taps and applies alpha, mask, -sub.
+ * Codes in the reference's (N,M,D,H,W) layout; map = (N,4,D,H,W) words as cdl_fused2d_support_map describes.
+ * precision: 0 (split-bf16 x3) only; CDL_TILES_REVERSED may be OR-ed in. */
+int cdl_fusedg_supported(const cdl_geom *g);
+size_t cdl_fusedg_frag_bytes(const cdl_geom *g);           /* bytes of one prepared (A_k, B_next) pair */
+size_t cdl_fusedg_patch_floats(const cdl_geom *g);
+size_t cdl_fusedg_tiles(const cdl_geom *g);                /* workgroup tiles (= dtau_partial rows) per launch */
+size_t cdl_fusedg_map_words(const cdl_geom *g);
+int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream);
+int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/, const float *tau /*N,M*/,
+                        const void *frags, float sgn, float *zout, float *patches, unsigned *map_out /*nullable*/,
+                        int precision, void *stream);
+int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base /*nullable*/, const unsigned *map,
+                         const void *frags, float *du_out, float *patches /*nullable iff !do_synth*/,
+                         float *dtau_partial /*tiles,M*/, int do_synth, int precision, void *stream);
+int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *mask /*nullable*/,
+                        const float *sub /*nullable*/, float alpha, float *out, void *stream);
+int cdl_fusedg_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c /*N, nullable*/, float *dt0,
+                           float *dt1, void *stream);
+/* Whole sweeps (arguments as cdl_fused2d_forward / _backward).  The reverse sweep takes the filter gradients
+ * dA_k = -du_k (x) r_k, dB_k = z_k (x) q_k from cdl_wgrad: wgrad_ws = cdl_wgrad_workspace_floats(g) floats. */
+int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/, const float *tau,
+                       const float *const *wA, const float *const *wB, float *const *z, float *const *r,
+                       unsigned *const *maps /*nullable*/, float *xp, void *frags, float *patches, int precision,
+                       void *stream);
+int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *mask /*nullable*/,
+                        const float *c /*nullable*/, const float *const *wA, const float *const *wB,
+                        const float *const *z, const float *const *r, const unsigned *const *maps, const float *g_xp,
+                        const float *g_z /*nullable*/, float *const *dA, float *const *dB, float *dt, float *du0,
+                        float *du1, float *q, void *frags, float *patches, float *dtau_partial, float *wgrad_ws,
+                        size_t wgrad_ws_floats, int precision, void *stream);
 
 /* Per-kernel timing inside the fused sweeps: cdl_fused2d_timing(1) starts collecting HIP-event pairs around
  * every forward stage (class 0; the k = 0 launch, which reads no code, is class 3), reverse stage (1) and

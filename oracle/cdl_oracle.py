@@ -130,17 +130,28 @@ def _thresholds(t, k, c):
     return t[k, :1] + c * t[k, 1:2]
 
 
-def ista_codes(yp, mask_p, A, B, t, c, s, pad):
-    """Generator over the K sparse codes z_1..z_K (reference forward_generator)."""
+def shrink_on_support(u, tau, code):
+    """ST(u, tau) with the support and signs PRESCRIBED by `code` (another evaluation's z_{k+1}):
+    [code != 0] * (u - sign(code) * tau).  Equals soft_threshold(u, tau) wherever the two evaluations
+    agree on the support; given the support, the net is a smooth (polynomial) function of its
+    parameters, so gradients of two fp32 evaluations can be compared tightly (tests only)."""
+    return (code != 0).to(u.dtype) * (u - torch.sign(code) * tau)
+
+
+def ista_codes(yp, mask_p, A, B, t, c, s, pad, supports=None):
+    """Generator over the K sparse codes z_1..z_K (reference forward_generator).
+    supports: optional K codes whose support / signs replace the shrinkage's own (shrink_on_support)."""
     K = len(A)
-    z = soft_threshold(analysis(yp, A[0], s, pad), _thresholds(t, 0, c))
+    st = (lambda u, tau, k: soft_threshold(u, tau)) if supports is None else \
+         (lambda u, tau, k: shrink_on_support(u, tau, supports[k]))
+    z = st(analysis(yp, A[0], s, pad), _thresholds(t, 0, c), 0)
     yield z
     for k in range(1, K):
         resid = synthesis(z, B[k], s, pad)
         if mask_p is not None:
             resid = mask_p * resid
         resid = resid - yp
-        z = soft_threshold(z - analysis(resid, A[k], s, pad), _thresholds(t, k, c))
+        z = st(z - analysis(resid, A[k], s, pad), _thresholds(t, k, c), k)
         yield z
 
 
@@ -159,7 +170,7 @@ def _weights_from_state(sd, K, gabor=None):
 
 
 def ista(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, ndim=2, gabor=False,
-         all_codes=False):
+         all_codes=False, supports=None):
     """Full forward: returns (xhat, z_K) or (xhat, [z_1..z_K]) when all_codes.
 
     `sd` maps the reference's state_dict keys to tensors.  `mask=None` is the
@@ -169,7 +180,7 @@ def ista(sd, y, *, K, P, s=1, sigma=None, adaptive=False, mask=None, ndim=2, gab
     c = 0.0 if (sigma is None or not adaptive) else sigma / 255.0
     pad = _conv_pad(P, ndim)
     A, B = _weights_from_state(sd, K, gabor=P if gabor else None)
-    codes = list(ista_codes(yp, mask_p, A, B, sd["t"], c, s, pad))
+    codes = list(ista_codes(yp, mask_p, A, B, sd["t"], c, s, pad, supports))
     xp = synthesis(codes[-1], B[0], s, pad)          # D is B[0] (net.py:34)
     xhat = postprocess(xp, mean, pads)
     return (xhat, codes) if all_codes else (xhat, codes[-1])
@@ -440,8 +451,10 @@ def trainable(sd, K, gabor=False):
     return keys
 
 
-def loss_and_grads(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, gabor=False):
-    """MSE(x, xhat) and d loss / d parameter for every trainable key (dict)."""
+def loss_and_grads(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, gabor=False, supports=None,
+                   code_weight=0.0):
+    """MSE(x, xhat) [+ code_weight * mean(z_K^2)] and d loss / d parameter for every trainable key (dict).
+    supports: see ista_codes."""
     keys = trainable(sd, K, gabor)
     leaves = {}
     work = dict(sd)
@@ -454,9 +467,11 @@ def loss_and_grads(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, gab
         for lk in keys:
             if val is sd[lk] and key != lk:
                 work[key] = leaves[lk]
-    xhat, _ = ista(work, y, K=K, P=P, s=s, sigma=sigma, adaptive=adaptive, mask=mask, ndim=ndim,
-                   gabor=gabor)
+    xhat, zK = ista(work, y, K=K, P=P, s=s, sigma=sigma, adaptive=adaptive, mask=mask, ndim=ndim,
+                    gabor=gabor, supports=supports)
     loss = torch.mean((x - xhat) ** 2)
+    if code_weight:
+        loss = loss + code_weight * torch.mean(zK ** 2)
     loss.backward()
     grads = {k: (leaves[k].grad if leaves[k].grad is not None else None) for k in keys}
     return float(loss.detach()), grads, xhat.detach()

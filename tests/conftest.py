@@ -48,3 +48,18 @@ def rel_err(a, b):
     """max|a-b| / max|b| (the parity metric of SURVEY.md 8(d))."""
     a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture
+def hip_env(monkeypatch):
+    """Setter for the library's CDL_* experiment switches: the library snapshots the environment once, so a
+    change is followed by cdl_options_reload(); the snapshot is refreshed again after monkeypatch has undone it."""
+    import cdlnet_video_amd as cva
+
+    def setenv(name, value):
+        monkeypatch.setenv(name, value)
+        cva._lib.reload_options()
+
+    yield setenv
+    monkeypatch.undo()
+    cva._lib.reload_options()

@@ -17,7 +17,9 @@ GTOL = 2e-4          # parameter gradients (sums over every pixel of products of
 
 CASES = [("f1_2d_s1", "2d"), ("f2_2d_s2_odd", "2d"), ("f3_jdd_c3_mask", "2d"), ("f3b_jdd_s2_odd", "2d"),
          ("f4a_3d_p555", "3d"), ("f4b_3d_p995_s2", "3d"), ("f4c_3d_s2_odd", "3d"),
-         ("f5_gabor_shared", "gabor"), ("f5b_gabor_plain", "gabor"), ("f6_negative_t", "2d")]
+         ("f5_gabor_shared", "gabor"), ("f5b_gabor_plain", "gabor"), ("f6_negative_t", "2d"),
+         # reference outputs on geometries the fused MFMA kernels take (tools/make_golden_fused.py)
+         ("f10_fused_m32_p7", "2d"), ("f11_fused_m64_p5", "2d")]
 
 
 def run_case(name, kind):

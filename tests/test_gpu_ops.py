@@ -53,11 +53,11 @@ def make(N, C, M, sp, P, s, seed=0):
 
 @pytest.mark.parametrize("path,tol", [("mfma", 2e-5), ("valu", 2e-6)])
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
-def test_analysis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
+def test_analysis_variants(N, C, M, sp, P, s, path, tol, hip_env):
     """Both analysis paths: the matrix-core kernel (default where it exists: >= 96 workgroups of 4 tiles; smaller
     launches fall through) and the fp32 VALU kernels (CDL_MFMA_ANALYSIS=0)."""
-    monkeypatch.setenv("CDL_MFMA_ANALYSIS", "1" if path == "mfma" else "0")
-    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_ANALYSIS", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s)
     pad = tuple(p // 2 for p in P)
@@ -81,11 +81,11 @@ def test_analysis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
 
 @pytest.mark.parametrize("path,tol", [("mfma", 2e-5), ("valu", 2e-6)])
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
-def test_synthesis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
+def test_synthesis_variants(N, C, M, sp, P, s, path, tol, hip_env):
     """Both synthesis paths: the matrix-core kernels (split-bf16 x3; default wherever they exist, the other
-    shapes fall through to the VALU kernels) and the fp32 VALU kernels (CDL_MFMA_SYNTHESIS=0, read per call)."""
-    monkeypatch.setenv("CDL_MFMA_SYNTHESIS", "1" if path == "mfma" else "0")
-    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
+    shapes fall through to the VALU kernels) and the fp32 VALU kernels (CDL_MFMA_SYNTHESIS=0; the library snapshots its switches, hip_env reloads them)."""
+    hip_env("CDL_MFMA_SYNTHESIS", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=1)
     pad = tuple(p // 2 for p in P)
@@ -106,11 +106,11 @@ def test_synthesis_variants(N, C, M, sp, P, s, path, tol, monkeypatch):
 
 @pytest.mark.parametrize("path", ["mfma", "valu"])
 @pytest.mark.parametrize("N,C,M,sp,P,s", SHAPES)
-def test_filter_and_threshold_grads(N, C, M, sp, P, s, path, monkeypatch):
+def test_filter_and_threshold_grads(N, C, M, sp, P, s, path, hip_env):
     """Filter gradients through the matrix-core kernel (default where it exists: >= 64 tiles of 64 x 32 code
     pixels; smaller launches fall through) and through the fp32 VALU kernels (CDL_MFMA_WGRAD=0)."""
-    monkeypatch.setenv("CDL_MFMA_WGRAD", "1" if path == "mfma" else "0")
-    monkeypatch.setenv("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_WGRAD", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_DENSE", "1" if path == "mfma" else "0")
     o = ops()
     x, z, w = make(N, C, M, sp, P, s, seed=2)
     pad = tuple(p // 2 for p in P)

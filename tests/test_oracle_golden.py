@@ -20,6 +20,8 @@ CASES = [
     ("f3b_jdd_s2_odd", 2, False), ("f4a_3d_p555", 3, False), ("f4b_3d_p995_s2", 3, False),
     ("f4c_3d_s2_odd", 3, False), ("f5_gabor_shared", 2, True), ("f5b_gabor_plain", 2, True),
     ("f6_negative_t", 2, False),
+    # geometries that enter the fused MFMA kernel (M = 32 / 64; tools/make_golden_fused.py)
+    ("f10_fused_m32_p7", 2, False), ("f11_fused_m64_p5", 2, False),
 ]
 
 
@@ -141,3 +143,20 @@ def test_helpers(golden):
     # only the defining property is checked: parity unpinned.
     w3 = O.unit_ball(g["W3"], (2, 3, 4))
     assert float(torch.linalg.vector_norm(w3, dim=(2, 3, 4)).max()) <= 1 + 1e-6
+
+
+def test_prescribed_support_reproduces_the_free_running_oracle(golden):
+    """shrink_on_support with the oracle's OWN codes as the prescription is the same function: outputs
+    and gradients equal the plain run (positive thresholds: bit for bit)."""
+    g = golden("f1_2d_s1")
+    K, M, P, s, C = hyper(g)
+    kw = dict(K=K, P=P, s=s, sigma=g["sigma"], adaptive=True)
+    xhat, codes = O.ista(g["sd"], g["y"], all_codes=True, **kw)
+    xhat2, codes2 = O.ista(g["sd"], g["y"], all_codes=True, supports=codes, **kw)
+    assert torch.equal(xhat, xhat2) and all(torch.equal(a, b) for a, b in zip(codes, codes2))
+    l1, g1, _ = O.loss_and_grads(g["sd"], g["x"], g["y"], **kw)
+    l2, g2, _ = O.loss_and_grads(g["sd"], g["x"], g["y"], supports=codes, **kw)
+    assert l1 == l2
+    for key in g1:
+        if g1[key] is not None:
+            assert rel_err(g2[key], g1[key]) < 1e-6, key

@@ -9,7 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                    # noqa: E402
-from cdlnet_video_amd import ops               # noqa: E402
+from cdlnet_video_amd import _lib, ops          # noqa: E402
 
 M, P, H, W = 64, 7, 256, 256
 gen = torch.Generator(device="cuda").manual_seed(3)
@@ -27,6 +27,7 @@ for N in (64, 8, 4):
         if G > tiles:
             continue
         os.environ["CDL_FUSED_GRID"] = str(G)
+        _lib.reload_options()
         for _ in range(3):
             ops.fused_iter(g, r, z, tau, frags, -1.0, patches, "split3", out=out)
         torch.cuda.synchronize()

@@ -21,5 +21,6 @@ def ev(fn, reps=20):
     return a.elapsed_time(b) / reps
 for dbg in (sys.argv[1:] or ("0", "1", "2", "3", "4", "6", "7")):
     os.environ["CDL_DENSE_DEBUG"] = dbg
+    cva._lib.reload_options()
     print("dbg", dbg, "analysis ms", round(ev(lambda: o.analysis(g, x, w1, out=out)), 4),
           "wgrad ms", round(ev(lambda: o.wgrad(g, out, x, 1.0, gate=x)), 4), flush=True)

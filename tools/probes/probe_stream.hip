@@ -1,0 +1,197 @@
+// GPU-box diagnostic: what a pure load -> store stream reaches on MI355X with the ACCESS SHAPES of the fused
+// iteration kernel (cdl_fused2d.hip), so that the kernel's 4.5-5.2 TB/s can be judged against a ceiling
+// measured on the same box rather than against torch's copy_.  Shapes (all move 2 x 1.07 GB = cfg2's code tensor):
+//   copy16      : grid-stride float4 copy, 2048 x 256 threads (the guide's 6.29 TB/s reference)
+//   plane       : persistent 512-thread workgroups, 64 x 32 pixel tiles, per 32-pixel row block of a wave 32
+//                 dword buffer loads whose addresses are one channel plane (H*W*4 B = 256 KiB) apart, then 32
+//                 dword stores of the same shape -- k_stage's fat accesses as they stand
+//   plane_pad   : the same with the channel planes 256 B further apart (stride H*W + 64 floats)
+//   blocked16   : the same tile walk on a pixel-blocked layout [n][y][x/32][M/4][32 px][4 ch]: a lane's 4
+//                 consecutive channels are 16 B, a wave instruction covers 1 KiB contiguous, a row block
+//                 8 KiB contiguous (8 dwordx4 loads + 8 dwordx4 stores)
+//   blocked8    : blocked layout with bf16 storage (4 channels = 8 B per lane; half the bytes)
+// PF = 1 variants issue the next row block's loads before storing the current one (two blocks in flight).
+// Output: one JSON line per variant with GB/s (median of REPS launches).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int N = 64, M = 64, H = 256, W = 256;
+constexpr int TW = 64, TH = 32, RB = 8;
+constexpr int OOB = 0x7fff0000;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+__global__ __launch_bounds__(256) void k_copy16(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void *base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+// k_stage's shape: lane (c, h) of wave (wxi, wyi) owns pixel column wxi*32 + c; register v of tile R is
+// channel 32R + 8(v>>2) + 4h + (v&3)
+template <int PF>
+__global__ __launch_bounds__(512) void k_plane(const float *__restrict__ in, float *__restrict__ out, int plane /*floats*/)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wxi = wid % 2, wyi = wid / 2, c = lane & 31, h = lane >> 5;
+    const int tilesX = W / TW, tilesY = H / TH, numTiles = N * tilesX * tilesY;
+    const size_t img = (size_t)M * plane;
+    const int hw4 = plane * 4;
+    for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
+        int bid = t;
+        const int txi = bid % tilesX; bid /= tilesX;
+        const int tyi = bid % tilesY;
+        const int n = bid / tilesY;
+        const int x = txi * TW + wxi * 32 + c;
+        const __amdgpu_buffer_rsrc_t ri = rsrc(in + (size_t)n * img, img * 4), ro = rsrc(out + (size_t)n * img, img * 4);
+        const int lane_off = (4 * h * plane + x) * 4;
+        float zc[2][32];
+        auto load = [&](int b, float (&dst)[32]) {
+            const int y = tyi * TH + wyi * RB + b;
+            const int voff = lane_off + y * W * 4;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int R = i >> 4, v = i & 15;
+                dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff, (32 * R + 8 * (v >> 2) + (v & 3)) * hw4, 0));
+            }
+        };
+        auto store = [&](int b, const float (&src)[32]) {
+            const int y = tyi * TH + wyi * RB + b;
+            const int voff = lane_off + y * W * 4;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int R = i >> 4, v = i & 15;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[i] + 1.0f), ro, voff, (32 * R + 8 * (v >> 2) + (v & 3)) * hw4, 0);
+            }
+        };
+        if (PF == 0) {
+#pragma unroll 1
+            for (int b = 0; b < RB; ++b) { load(b, zc[0]); store(b, zc[0]); }
+        } else {
+            load(0, zc[0]);
+#pragma unroll 1
+            for (int b = 0; b < RB; b += 2) {
+                load(b + 1, zc[1]);
+                store(b, zc[0]);
+                if (b + 2 < RB) load(b + 2, zc[0]);
+                store(b + 1, zc[1]);
+            }
+        }
+    }
+}
+
+// blocked layout: [n][y][xb][q = M/4][32 px][4 ch]; EB = bytes per lane access (16: fp32, 8: bf16)
+template <int PF, int EB>
+__global__ __launch_bounds__(512) void k_blocked(const char *__restrict__ in, char *__restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wxi = wid % 2, wyi = wid / 2, c = lane & 31, h = lane >> 5;
+    const int tilesX = W / TW, tilesY = H / TH, numTiles = N * tilesX * tilesY;
+    constexpr int XB = W / 32, Q = M / 4;
+    constexpr size_t rowblk = (size_t)Q * 32 * EB;              // bytes of one (y, xb) block: 8 KiB fp32
+    const size_t img = (size_t)H * XB * rowblk;
+    typedef typename std::conditional<EB == 16, u32x4, u32x2>::type vec;
+    for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
+        int bid = t;
+        const int txi = bid % tilesX; bid /= tilesX;
+        const int tyi = bid % tilesY;
+        const int n = bid / tilesY;
+        const int xb = txi * 2 + wxi;
+        const __amdgpu_buffer_rsrc_t ri = rsrc(in + (size_t)n * img, img), ro = rsrc(out + (size_t)n * img, img);
+        vec zc[2][8];
+        auto load = [&](int b, vec (&dst)[8]) {
+            const int y = tyi * TH + wyi * RB + b;
+            const int voff = (int)(((size_t)y * XB + xb) * rowblk) + (h * 32 + c) * EB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                       // quad 2i + h: R = i >> 2, v>>2 = i & 3
+                if constexpr (EB == 16) dst[i] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(ri, voff, i * 2 * 32 * EB, 0));
+                else dst[i] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b64(ri, voff, i * 2 * 32 * EB, 0));
+            }
+        };
+        auto store = [&](int b, vec (&src)[8]) {
+            const int y = tyi * TH + wyi * RB + b;
+            const int voff = (int)(((size_t)y * XB + xb) * rowblk) + (h * 32 + c) * EB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vec v = src[i];
+                v.x += 1u;
+                if constexpr (EB == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, voff, i * 2 * 32 * EB, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, voff, i * 2 * 32 * EB, 0);
+            }
+        };
+        if (PF == 0) {
+#pragma unroll 1
+            for (int b = 0; b < RB; ++b) { load(b, zc[0]); store(b, zc[0]); }
+        } else {
+            load(0, zc[0]);
+#pragma unroll 1
+            for (int b = 0; b < RB; b += 2) {
+                load(b + 1, zc[1]);
+                store(b, zc[0]);
+                if (b + 2 < RB) load(b + 2, zc[0]);
+                store(b + 1, zc[1]);
+            }
+        }
+    }
+}
+
+template <class F>
+static double time_ms(F launch, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch();
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, 0));
+        launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[i], e0, e1));
+    }
+    CK(hipGetLastError());
+    std::sort(ms.begin(), ms.end());
+    return ms[reps / 2];
+}
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? atoi(argv[1]) : 15;
+    const size_t floats = (size_t)N * M * (H * W + 64);         // room for the padded planes
+    float *in, *out;
+    CK(hipMalloc(&in, floats * 4)); CK(hipMalloc(&out, floats * 4));
+    CK(hipMemset(in, 0x3c, floats * 4)); CK(hipMemset(out, 0, floats * 4));
+    const double bytes = 2.0 * N * M * H * W * 4;
+    int cus = 256;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    auto report = [&](const char *name, int grid, double ms, double b) {
+        printf("{\"probe\": \"%s\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f, \"frac_of_8TBps\": %.3f}\n", name, grid, ms, b / ms * 1e-6,
+               b / ms * 1e-6 / 8000.0);
+        fflush(stdout);
+    };
+    const size_t n4 = (size_t)N * M * H * W / 4;
+    for (int g : {2048, 8192})
+        report("copy16 (float4 grid-stride, 256 threads)", g,
+               time_ms([&] { k_copy16<<<g, 256>>>((const float4 *)in, (float4 *)out, n4); }, reps), bytes);
+    for (int g : {cus, 2 * cus}) {
+        report("plane dword, stride H*W (k_stage today)", g, time_ms([&] { k_plane<0><<<g, 512>>>(in, out, H * W); }, reps), bytes);
+        report("plane dword, stride H*W, 2 row blocks in flight", g, time_ms([&] { k_plane<1><<<g, 512>>>(in, out, H * W); }, reps), bytes);
+        report("plane dword, stride H*W+64", g, time_ms([&] { k_plane<0><<<g, 512>>>(in, out, H * W + 64); }, reps), bytes);
+        report("plane dword, stride H*W+64, 2 row blocks in flight", g, time_ms([&] { k_plane<1><<<g, 512>>>(in, out, H * W + 64); }, reps), bytes);
+        report("blocked 16 B (1 KiB per instruction)", g, time_ms([&] { k_blocked<0, 16><<<g, 512>>>((const char *)in, (char *)out); }, reps), bytes);
+        report("blocked 16 B, 2 row blocks in flight", g, time_ms([&] { k_blocked<1, 16><<<g, 512>>>((const char *)in, (char *)out); }, reps), bytes);
+        report("blocked 8 B (bf16 storage)", g, time_ms([&] { k_blocked<0, 8><<<g, 512>>>((const char *)in, (char *)out); }, reps), bytes / 2);
+        report("blocked 8 B (bf16 storage), 2 row blocks in flight", g, time_ms([&] { k_blocked<1, 8><<<g, 512>>>((const char *)in, (char *)out); }, reps), bytes / 2);
+    }
+    return 0;
+}
