@@ -30,6 +30,7 @@
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -457,6 +458,10 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     float tsum[MT * 16];                     // backward: per-lane partial threshold gradients
 #pragma unroll
     for (int i = 0; i < MT * 16; ++i) tsum[i] = 0.0f;
+    // thresholds are >= 0 whenever project() runs (net.py:70); a negative one (3-D trainer, never projected) sends
+    // the whole tile through the general shrinkage -- wave-uniform, so the common case pays 3 instructions per
+    // element (u - clamp(u, -t, t)) instead of 10
+    const bool tau_neg = MODE != MODE_BWD && __ballot(lane < M && tau_s[lane] < 0.0f) != 0ull;
     float taur[MT * 16];                     // forward: this lane's 16 MT thresholds
     if (MODE != MODE_BWD) {
 #pragma unroll
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
         __builtin_amdgcn_sched_barrier(0);
         // -- epilogue
+        auto epilogue = [&](auto general_shrink) {
 #pragma unroll
         for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -578,12 +584,19 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 } else {
                     const float base = (MODE == MODE_FWD) ? zbase : 0.0f;
                     const float u = fmaf(p.sgn, acc[R][v], base);
-                    zz = (p.dbg & 64) ? u : (valid ? cdl_shrink(u, taur[16 * R + v]) : 0.0f);
+                    // t >= 0: sign(u) relu(|u| - t) == u - clamp(u, -t, t) with the same rounding; NaN in u stays NaN
+                    const float tt = taur[16 * R + v];
+                    const float st = decltype(general_shrink)::value ? cdl_shrink(u, tt)
+                                                                     : u - __builtin_amdgcn_fmed3f(u, -tt, tt);
+                    zz = (p.dbg & 64) ? u : (valid ? st : 0.0f);
                 }
                 if (LOUT == LAY_BLK16) zz = bf16_round(zz);             // the code IS its stored value from here on
                 if (LOUT == LAY_NCHW) buf_st(zz, rs_out, voff_st, chl * hw4);
                 acc[R][v] = zz;
             }
+        };
+        if (tau_neg) epilogue(std::true_type{});   // wave-uniform
+        else epilogue(std::false_type{});
         if (LOUT != LAY_NCHW) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)

@@ -69,6 +69,9 @@ struct GParams {
     float sgn;
     int do_synth;
     int N, C, M, D, H, W, Pd, tilesX, tilesY, KS, rev;
+    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG; results are wrong): 1 no thin staging after the
+                             // first tile, 2 no analysis GEMM, 4 no synthesis / col2im, 8 no fat loads, 16 no fat stores,
+                             // 32 no patch combine
 };
 
 __device__ __forceinline__ float wave_shr1(float v)
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
     constexpr int WPW = 32 + P - 1, WPH = RB + P - 1, WPE = WPH * WPW;      // wave patch
     constexpr int PY = TH + P - 1, PX = TW + P - 1;                          // tile patch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int KS = p.KS, M = p.M;
+    constexpr int KS = (G * P * P + 15) / 16;               // 16-tap k-steps of the analysis-like GEMM (== p.KS)
+    const int M = p.M;
     const int KQ = (M + 15) / 16;                            // 16-channel k-steps of the synthesis-like GEMM
     const Carve cv = carve<P>(MT, KS, KQ, G, PREC);
     const uint4 *wa = reinterpret_cast<const uint4 *>(smem + cv.wa);
@@ -249,16 +253,68 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 const int q = k / P;
                 o = (q / P) * PS + (q % P) * XW + kj;       // plane (c*Pd + kd), row ki, column kj
             }
-            koff[k] = o;
+            koff[k] = cv.xh + 2 * o;                        // BYTE address of the tap in the hi planes (lo: + cv.xl - cv.xh)
         }
     }
     const int OFF_AL = FA, OFF_BL = FB;                      // lo fragments follow the hi ones (split3 only)
     auto afrag = [&](int f) { return __builtin_bit_cast(bf16x8, wa[f * 64 + lane]); };
     auto bfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wb[f * 64 + lane]); };
     float *wp = wp_all + (size_t)wid * G * WPE;
+    // this thread's elements of a thin plane and of a tile patch row group: (row, column) computed once, so the
+    // per-tile loops below run without integer divisions
+    constexpr int NSTG = (XH * XW + NT - 1) / NT;
+    int stg_row[NSTG], stg_col[NSTG];
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) {
+        const int i = tid + k * NT;
+        stg_row[k] = i < XH * XW ? i / XW : -1000000;       // rows far outside: the bounds test below drops them
+        stg_col[k] = i % XW;
+    }
+    constexpr int CROWS = NT / PX;                           // patch rows handled per pass of the combine
+    const int cmb_row = tid / PX, cmb_col = tid % PX;
     const int up_addr = ((lane & 31) + 32) * 4;              // ds_bpermute byte address of the lane 32 above
+    const int lo_delta = cv.xl - cv.xh;                      // hi plane -> lo plane, bytes
     const bool has_base = (MODE == MODE_FWD) || (MODE == MODE_BWD && p.zin != nullptr);
     const int dhw4 = (int)DHW * 4;
+
+    // thin planes of a tile: plane g = (c, kd) is depth zd - Pd/2 + kd of channel c.  Loaded into registers one tile
+    // ahead (after the row loop of the previous tile, so the loads fly during its patch combine), converted and
+    // stored to LDS at the top of the tile.
+    float stg[G][NSTG];
+    auto stage_load = [&](int t) {
+        int bid = p.rev ? numTiles - 1 - t : t;
+        const int txi = bid % p.tilesX; bid /= p.tilesX;
+        const int tyi = bid % p.tilesY; bid /= p.tilesY;
+        const int zd = bid % p.D, n = bid / p.D;
+        const bool skip = t >= numTiles || ((p.dbg & 1) && t != (int)blockIdx.x);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int kd = g % p.Pd, cc = g / p.Pd;
+            const int d = zd - p.Pd / 2 + kd;
+            const bool dok = !skip && d >= 0 && d < p.D;
+            const float *plane = p.r + (((size_t)n * p.C + cc) * p.D + (dok ? d : 0)) * HW;
+#pragma unroll
+            for (int k = 0; k < NSTG; ++k) {
+                const int yy = tyi * TH - HALO + stg_row[k], xx = txi * TW - HALO + stg_col[k];
+                stg[g][k] = (dok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? plane[yy * p.W + xx] : 0.0f;
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < NSTG; ++k) {
+                const int i = tid + k * NT;
+                const float v = stg[g][k];
+                const __bf16 hh = (__bf16)v;
+                if (i < XH * XW) {
+                    xh[g * PS + i] = hh;
+                    if (PREC == 0) xl[g * PS + i] = (__bf16)(v - (float)hh);
+                }
+            }
+    };
+    stage_load(blockIdx.x);
 
 #pragma unroll 1
     for (int t = blockIdx.x; t < numTiles; t += gridDim.x) {
@@ -269,21 +325,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
         const int zd = bid % p.D, n = bid / p.D;
         const int tx0 = txi * TW, ty0 = tyi * TH;
         __syncthreads();                                     // previous tile's readers are done (and the tables are in)
-        // ---- thin planes of this tile: plane g = (c, kd) is depth zd - Pd/2 + kd of channel c
-        for (int g = 0; g < G; ++g) {
-            const int kd = g % p.Pd, cc = g / p.Pd;
-            const int d = zd - p.Pd / 2 + kd;
-            const bool dok = d >= 0 && d < p.D;
-            const float *plane = p.r + (((size_t)n * p.C + cc) * p.D + (dok ? d : 0)) * HW;
-            for (int i = tid; i < XH * XW; i += NT) {
-                const int col = i % XW, row = i / XW;
-                const int yy = ty0 - HALO + row, xx = tx0 - HALO + col;
-                const float v = (dok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? plane[(size_t)yy * p.W + xx] : 0.0f;
-                const __bf16 hh = (__bf16)v;
-                xh[g * PS + i] = hh;
-                if (PREC == 0) xl[g * PS + i] = (__bf16)(v - (float)hh);
-            }
-        }
+        stage_store();                                       // thin planes of this tile (loaded into registers earlier)
         if (MODE != MODE_BWD && tid < 64) tau_s[tid] = tid < M ? p.tau[(size_t)n * M + tid] : 0.0f;
         for (int i = lane; i < G * WPE; i += 64) wp[i] = 0.0f;          // this wave's private patch
         __syncthreads();
@@ -308,26 +350,45 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
             p.zout + (size_t)n * M * DHW, 0, (int)(M * DHW * 4), 0x00020000);
         unsigned *const map_n = p.map ? p.map + (((size_t)n * 4 + 2 * h) * p.D + zd) * HW : nullptr;
-        const int lane_off = (int)((4 * h) * DHW + (size_t)zd * HW + x) * 4;
+        // per-lane part of a fat address: channel half 4h and pixel column (tile invariant); the row and the channel
+        // travel in the scalar offset, built per row block by a running scalar sum (32 precomputed channel offsets
+        // held across the row loop cost 100+ spilled SGPRs in the first version)
+        const int voff_x = xok ? (int)((4 * h) * DHW + x) * 4 : OOB;
 
 #pragma unroll 1
         for (int b = 0; b < RB; ++b) {
             const int yl = wyi * RB + b, y = ty0 + yl;
-            const bool valid = xok && y < p.H;
-            const int voff = valid ? lane_off + y * p.W * 4 : OOB;
-            // channels >= M (M < 32 MT) are masked through the per-lane offset: the scalar channel offset does not
-            // take part in the buffer range check, so they must not reach the address at all
-            auto ch_off = [&](int chl) { return (chl + 4 * h < M) ? voff : OOB; };
+            const bool rowok = y < p.H;                          // uniform
+            const bool valid = xok && rowok;
+            const int voff = rowok ? voff_x : OOB;
+            const int voff_st = (p.dbg & 16) ? OOB : voff;
+            // (y depends on the wave index: wave-uniform, but only readfirstlane makes that provable -- otherwise every
+            //  buffer access below gets a waterfall loop around its scalar offset)
+            const int s_row = __builtin_amdgcn_readfirstlane((int)((size_t)zd * HW + (size_t)y * p.W) * 4);
+            // (M is a multiple of 8: a register quad of 4 channels x 2 lane halves is either all real or all padding,
+            //  so padding channels are skipped by uniform branches and never reach an address)
 
             // -- fat inputs of this block, issued first
             float zc[MT][16];
-            if (MODE != MODE_FIRST) {
+            if (MODE != MODE_FIRST && (p.dbg & 8)) {
 #pragma unroll
                 for (int R = 0; R < MT; ++R)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        zc[R][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_in, ch_off(32 * R + 8 * (v >> 2) + (v & 3)), (32 * R + 8 * (v >> 2) + (v & 3)) * dhw4, 0));
+                    for (int v = 0; v < 16; ++v) zc[R][v] = 0.25f;
+            } else if (MODE != MODE_FIRST) {
+                int so = s_row;
+#pragma unroll
+                for (int R = 0; R < MT; ++R)
+#pragma unroll
+                    for (int qv = 0; qv < 4; ++qv) {
+                        if (32 * R + 8 * qv < M) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                zc[R][4 * qv + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    rs_in, voff, so + e * dhw4, 0));
+                        }
+                        so += 8 * dhw4;
+                    }
             }
             unsigned sup = 0, sgb = 0;
             if (MODE == MODE_BWD && valid) {
@@ -336,22 +397,25 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             }
 
             // -- analysis-like GEMM: im2col gathered through the offset table
-            const int pixbase = yl * XW + wxi * 32 + c;
+            const int pixbase = 2 * (yl * XW + wxi * 32 + c);   // bytes
             f32x16 acc[MT];
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-#pragma unroll 1
+#pragma unroll 2
             for (int ks = 0; ks < KS; ++ks) {
+                if (p.dbg & 2) { acc[0][0] += (float)ks; continue; }
                 const int4 o0 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h);
                 const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
                 const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 bf16x8 bh, bl;
+                // one address add per tap; the lo plane is the same address + a constant that fits the DS offset field
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    bh[i] = xh[oo[i] + pixbase];
-                    if (PREC == 0) bl[i] = xl[oo[i] + pixbase];
+                    const unsigned char *pt = smem + (oo[i] + pixbase);
+                    bh[i] = *reinterpret_cast<const __bf16 *>(pt);
+                    if (PREC == 0) bl[i] = *reinterpret_cast<const __bf16 *>(pt + lo_delta);
                 }
 #pragma unroll
                 for (int R = 0; R < MT; ++R) {
@@ -368,10 +432,11 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             __builtin_amdgcn_sched_barrier(0);
             // -- epilogue: register v of tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
             auto epilogue = [&](auto general_shrink) {
+            int so = s_row;
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
-                for (int qv = 0; qv < 4; ++qv) {
+                for (int qv = 0; qv < 4; ++qv, so += 8 * dhw4) {
                     if (32 * R + 8 * qv >= M) {              // uniform: both channel quads of this register quad are padding
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[R][4 * qv + e] = 0.0f;
@@ -385,8 +450,6 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int v = 4 * qv + e;
-                        const int chl = 32 * R + 8 * qv + e;             // + 4h folded into lane_off
-                        const bool live = valid && (chl + 4 * h < M);
                         float zz;
                         if (MODE == MODE_BWD) {
                             const bool on = (sup >> (16 * R + v)) & 1u;   // never set for out-of-image lanes / padding channels
@@ -398,9 +461,9 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                             // t >= 0: sign(u) relu(|u| - t) == u - clamp(u, -t, t), same rounding, NaN in u stays NaN
                             zz = decltype(general_shrink)::value ? cdl_shrink(u, t4[e])
                                                                  : u - __builtin_amdgcn_fmed3f(u, -t4[e], t4[e]);
-                            zz = live ? zz : 0.0f;
+                            zz = valid ? zz : 0.0f;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), rs_out, ch_off(chl), chl * dhw4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), rs_out, voff_st, so + e * dhw4, 0);
                         acc[R][v] = zz;
                     }
                 }
@@ -423,6 +486,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 }
             }
             if (MODE == MODE_BWD && !p.do_synth) continue;
+            if (p.dbg & 4) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
             __builtin_amdgcn_sched_barrier(0);
             // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand; split once,
@@ -439,10 +503,15 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                f32x16 Dt[RT];
+                // One 32-row tap tile at a time (P = 7: filter rows 0-3 live in tile 0, rows 4-6 in tile 1), so only one
+                // accumulator tile is live.  col2im, column direction: for filter row i, sum over j of tap (i, j) shifted
+                // right by j lanes; lane L (0 .. 32+P-2) ends with the contribution to output column x0 - HALO + L.  The
+                // rows of a tile run as independent Horner chains side by side (no DPP wait states to pad); taps that sit
+                // in the upper lane half are fetched with one cross-lane read each.  Row direction: tap row i of image
+                // row y lands on output row y - HALO + i = ring slot i.
 #pragma unroll
                 for (int Rt = 0; Rt < RT; ++Rt) {
-                    Dt[Rt] = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    f32x16 Dt = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int q = 0; q < 2 * MT; ++q) {
                         if (q >= KQ) break;                  // uniform: channels beyond M
@@ -450,33 +519,30 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                         const bf16x8 wh = bfrag(f);
                         if (PREC == 0) {
                             const bf16x8 wl = bfrag(OFF_BL + f);
-                            Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt[Rt], 0, 0, 0);
-                            Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt[Rt], 0, 0, 0);
+                            Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt, 0, 0, 0);
+                            Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt, 0, 0, 0);
                         }
-                        Dt[Rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh[q], Dt[Rt], 0, 0, 0);
+                        Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh[q], Dt, 0, 0, 0);
                     }
+                    float sr[P];
+#pragma unroll
+                    for (int i = 0; i < P; ++i) sr[i] = 0.0f;
+#pragma unroll
+                    for (int j = P - 1; j >= 0; --j)
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            const int slot = tap_slot<P>(i, j);
+                            if ((slot >> 5) != Rt) continue;     // compile time: this row's taps are in the other tile
+                            const int v = 4 * ((slot >> 3) & 3) + (slot & 3), hh = (slot >> 2) & 1;
+                            float val = Dt[v];
+                            if (hh)                              // lanes 0..31 read lanes 32..63
+                                val = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up_addr, __builtin_bit_cast(int, val)));
+                            sr[i] = wave_shr1(sr[i]) + (h == 0 ? val : 0.0f);
+                        }
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+                        if ((tap_slot<P>(i, 0) >> 5) == Rt) ring[g][i] += sr[i];
                 }
-                // -- col2im, column direction: for filter row i, sum over j of tap (i, j) shifted right by j lanes;
-                //    lane L (0 .. 32+P-2) ends with the contribution to output column x0 - HALO + L.  The P rows run as
-                //    independent Horner chains side by side (no DPP wait states to pad); taps that sit in the upper lane
-                //    half are fetched with one cross-lane read each.  Row direction: tap row i of image row y lands on
-                //    output row y - HALO + i = ring slot i.
-                float sr[P];
-#pragma unroll
-                for (int i = 0; i < P; ++i) sr[i] = 0.0f;
-#pragma unroll
-                for (int j = P - 1; j >= 0; --j)
-#pragma unroll
-                    for (int i = 0; i < P; ++i) {
-                        const int slot = tap_slot<P>(i, j);
-                        const int Rt = slot >> 5, v = 4 * ((slot >> 3) & 3) + (slot & 3), hh = (slot >> 2) & 1;
-                        float val = Dt[Rt][v];
-                        if (hh)                              // lanes 0..31 read lanes 32..63
-                            val = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up_addr, __builtin_bit_cast(int, val)));
-                        sr[i] = wave_shr1(sr[i]) + (h == 0 ? val : 0.0f);
-                    }
-#pragma unroll
-                for (int i = 0; i < P; ++i) ring[g][i] += sr[i];
                 // ring slot 0 is complete after this block: one plain LDS store per lane into the wave's own patch
                 if (lane < WPW) wp[g * WPE + b * WPW + lane] = ring[g][0];
 #pragma unroll
@@ -502,6 +568,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tot;
             }
         }
+        stage_load(t + gridDim.x);                           // next tile's thin loads fly during the combine below
         __syncthreads();                                     // every wave's patch (and tacc) is complete
         if (MODE == MODE_BWD && tid < 64) {
             float sacc = 0.0f;
@@ -509,25 +576,24 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             for (int w = 0; w < NW; ++w) sacc += tacc_s[w * 64 + tid];
             if (tid < M) p.dtau[(size_t)tile * M + tid] = sacc;
         }
-        if (MODE != MODE_BWD || p.do_synth) {
-            // tile patch = fixed-order sum (wave row, then wave column) of the wave patches covering each element
+        if ((MODE != MODE_BWD || p.do_synth) && !(p.dbg & 32)) {
+            // tile patch = fixed-order sum (wave row, then wave column) of the wave patches covering each element;
+            // CROWS patch rows per pass, one thread per element
             float *patch = p.patches + (size_t)tile * G * (PY * PX);
-            for (int o = tid; o < G * PY * PX; o += NT) {
-                const int g = o / (PY * PX), rem = o % (PY * PX);
-                const int Y = rem / PX, X = rem % PX;
-                float sum = 0.0f;
+            if (cmb_row < CROWS) {
+                const int wx_lo = cmb_col >= 32 ? 1 : 0, wx_hi = cmb_col < WPW ? 0 : 1;      // waves (x) covering this column
+                for (int rr = cmb_row; rr < G * PY; rr += CROWS) {
+                    const int g = rr / PY, Y = rr - g * PY;
+                    float sum = 0.0f;
 #pragma unroll
-                for (int wy = 0; wy < WY; ++wy) {
-                    const int ry = Y - wy * RB;
-                    if (ry < 0 || ry >= WPH) continue;
-#pragma unroll
-                    for (int wx = 0; wx < WX; ++wx) {
-                        const int rx = X - wx * 32;
-                        if (rx < 0 || rx >= WPW) continue;
-                        sum += wp_all[((size_t)(wy * WX + wx) * G + g) * WPE + ry * WPW + rx];
+                    for (int wy = 0; wy < WY; ++wy) {
+                        const int ry = Y - wy * RB;
+                        if (ry < 0 || ry >= WPH) continue;
+                        for (int wx = wx_hi; wx <= wx_lo; ++wx)
+                            sum += wp_all[((size_t)(wy * WX + wx) * G + g) * WPE + ry * WPW + (cmb_col - wx * 32)];
                     }
+                    patch[rr * PX + cmb_col] = sum;
                 }
-                patch[o] = sum;
             }
         }
     }
@@ -606,7 +672,7 @@ bool plan_for(const cdl_geom *g, Plan *pl)
     if (g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
     if (g->Ph != g->Pw || (g->Ph != 3 && g->Ph != 5 && g->Ph != 7)) return false;
     if ((g->Pd & 1) == 0 || g->pd != g->Pd / 2 || g->ph != g->Ph / 2 || g->pw != g->Pw / 2) return false;
-    if (g->M > 64 || g->M < 1) return false;
+    if (g->M > 64 || g->M < 8 || (g->M & 7)) return false;  // whole register quads of channels (see k_stage_g)
     pl->P = g->Ph;
     pl->G = g->C * g->Pd;
     if (pl->G != 1 && pl->G != 3 && pl->G != 5 && pl->G != 7) return false;
@@ -670,6 +736,7 @@ int launch_p(const GParams &p, const Plan &pl, int mode, hipStream_t st)
 int dispatch(const cdl_geom *g, GParams &p, const Plan &pl, int mode, int precision, hipStream_t st)
 {
     p.rev = (precision >> 4) & 1;
+    p.dbg = cdl_opts().fused_debug;
     if ((precision >> 5) != 0) return CDL_EINVAL;
     if ((precision & 15) != 0) return CDL_EUNSUPPORTED;      // split-bf16 x3 only
     p.N = g->N; p.C = g->C; p.M = g->M; p.D = g->D; p.H = g->H; p.W = g->W; p.Pd = g->Pd;

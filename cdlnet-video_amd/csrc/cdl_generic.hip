@@ -493,6 +493,73 @@ __global__ void k_gabor_bwd(const float *__restrict__ alpha, const float *__rest
     dpsi[q] = g_ps;
 }
 
+// every bank of a net in ONE launch (blockIdx.y = bank): GDLNet re-synthesises its 2K banks on every forward
+// (gabor.py:46-51 via net.py:659-675) -- per-bank launches made that 2K launches + 2K autograd nodes per sweep
+constexpr int GABOR_BATCH = 48;
+struct GaborBatch {
+    const float *alpha[GABOR_BATCH], *a[GABOR_BATCH], *w0[GABOR_BATCH], *psi[GABOR_BATCH];
+    const float *dw[GABOR_BATCH];            // backward: upstream filter gradient (nullptr: this bank got none)
+    float *out[GABOR_BATCH];                 // forward: filters (M,C,P,P); backward: [dalpha | da | dw0 | dpsi] block
+    float sgn[GABOR_BATCH];                  // -1 for the analysis (transpose) filter
+};
+
+__global__ void k_gabor_batch(GaborBatch b, int order, int MC, int P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i >= MC * P * P) return;
+    const float *alpha = b.alpha[k], *a = b.a[k], *w0 = b.w0[k], *psi = b.psi[k];
+    const float sgn = b.sgn[k];
+    int kj = i % P, ki = (i / P) % P, mc = i / (P * P);
+    float gy = (float)ki - 0.5f * (P - 1), gx = (float)kj - 0.5f * (P - 1);
+    float acc = 0.0f;
+    for (int o = 0; o < order; ++o) {
+        int q = o * MC + mc;
+        float e0 = a[2 * q] * gy, e1 = a[2 * q + 1] * gx;
+        float env = expf(-(e0 * e0 + e1 * e1));
+        float ph = sgn * w0[2 * q] * gy + sgn * w0[2 * q + 1] * gx + sgn * psi[q];
+        acc += alpha[q] * (env * cosf(ph));
+    }
+    b.out[k][i] = acc;
+}
+
+// out block of bank k: dalpha (order*MC) | da (2*order*MC) | dw0 (2*order*MC) | dpsi (order*MC); zeros when dw is null
+__global__ void k_gabor_bwd_batch(GaborBatch b, int order, int MC, int P)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    const int nq = order * MC;
+    if (q >= nq) return;
+    float *out = b.out[k];
+    float g_al = 0, g_a0 = 0, g_a1 = 0, g_f0 = 0, g_f1 = 0, g_ps = 0;
+    const float *dw = b.dw[k];
+    if (dw) {
+        const float sgn = b.sgn[k];
+        const int mc = q % MC;
+        const float al = b.alpha[k][q], a0 = b.a[k][2 * q], a1 = b.a[k][2 * q + 1];
+        const float f0 = sgn * b.w0[k][2 * q], f1 = sgn * b.w0[k][2 * q + 1], ps = sgn * b.psi[k][q];
+        for (int ki = 0; ki < P; ++ki)
+            for (int kj = 0; kj < P; ++kj) {
+                float gy = (float)ki - 0.5f * (P - 1), gx = (float)kj - 0.5f * (P - 1);
+                float e0 = a0 * gy, e1 = a1 * gx;
+                float env = expf(-(e0 * e0 + e1 * e1));
+                float ph = f0 * gy + f1 * gx + ps;
+                float cs = cosf(ph), sn = sinf(ph);
+                float up = dw[(size_t)mc * P * P + ki * P + kj];
+                g_al += up * env * cs;
+                float de = up * al * cs * env;
+                g_a0 += de * (-2.0f * a0 * gy * gy);
+                g_a1 += de * (-2.0f * a1 * gx * gx);
+                float dp = -up * al * env * sn;
+                g_f0 += dp * sgn * gy;
+                g_f1 += dp * sgn * gx;
+                g_ps += dp * sgn;
+            }
+    }
+    out[q] = g_al;
+    out[nq + 2 * q] = g_a0; out[nq + 2 * q + 1] = g_a1;
+    out[3 * nq + 2 * q] = g_f0; out[3 * nq + 2 * q + 1] = g_f1;
+    out[5 * nq + q] = g_ps;
+}
+
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -827,6 +894,50 @@ int cdl_gabor_filters(const float *alpha, const float *a, const float *w0, const
     k_gabor<<<(total + 255) / 256, 256, 0, S(stream)>>>(alpha, a, w0, psi, w, order, M * C, P,
                                                         transpose ? -1.0f : 1.0f);
     CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_gabor_filter_banks(int nbanks, const float *const *alpha, const float *const *a, const float *const *w0,
+                           const float *const *psi, const int *transpose, float *const *w, int order, int M, int C,
+                           int P, void *stream)
+{
+    if (nbanks <= 0 || !alpha || !a || !w0 || !psi || !transpose || !w || order <= 0 || M <= 0 || C <= 0 || P <= 0)
+        return CDL_EINVAL;
+    const int total = M * C * P * P;
+    for (int k0 = 0; k0 < nbanks; k0 += GABOR_BATCH) {
+        const int nb = nbanks - k0 < GABOR_BATCH ? nbanks - k0 : GABOR_BATCH;
+        GaborBatch b = {};
+        for (int i = 0; i < nb; ++i) {
+            const int k = k0 + i;
+            if (!alpha[k] || !a[k] || !w0[k] || !psi[k] || !w[k]) return CDL_EINVAL;
+            b.alpha[i] = alpha[k]; b.a[i] = a[k]; b.w0[i] = w0[k]; b.psi[i] = psi[k]; b.out[i] = w[k];
+            b.sgn[i] = transpose[k] ? -1.0f : 1.0f;
+        }
+        k_gabor_batch<<<dim3((unsigned)((total + 255) / 256), (unsigned)nb), 256, 0, S(stream)>>>(b, order, M * C, P);
+        CDL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int cdl_gabor_filter_banks_bwd(int nbanks, const float *const *alpha, const float *const *a, const float *const *w0,
+                               const float *const *psi, const int *transpose, const float *const *dw, float *const *grads,
+                               int order, int M, int C, int P, void *stream)
+{
+    if (nbanks <= 0 || !alpha || !a || !w0 || !psi || !transpose || !dw || !grads || order <= 0 || M <= 0 || C <= 0 || P <= 0)
+        return CDL_EINVAL;
+    const int total = order * M * C;
+    for (int k0 = 0; k0 < nbanks; k0 += GABOR_BATCH) {
+        const int nb = nbanks - k0 < GABOR_BATCH ? nbanks - k0 : GABOR_BATCH;
+        GaborBatch b = {};
+        for (int i = 0; i < nb; ++i) {
+            const int k = k0 + i;
+            if (!alpha[k] || !a[k] || !w0[k] || !psi[k] || !grads[k]) return CDL_EINVAL;
+            b.alpha[i] = alpha[k]; b.a[i] = a[k]; b.w0[i] = w0[k]; b.psi[i] = psi[k]; b.dw[i] = dw[k]; b.out[i] = grads[k];
+            b.sgn[i] = transpose[k] ? -1.0f : 1.0f;
+        }
+        k_gabor_bwd_batch<<<dim3((unsigned)((total + 63) / 64), (unsigned)nb), 64, 0, S(stream)>>>(b, order, M * C, P);
+        CDL_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -26,6 +26,41 @@ class _GaborBank(torch.autograd.Function):
         return dal, da, dw0, dpsi, None, None
 
 
+class _GaborBanks(torch.autograd.Function):
+    """(P, transposes, alpha_0, a_0, w0_0, psi_0, alpha_1, ...) -> every filter bank of a net, one launch each way.
+    Aliased parameters (GDLNet's `shared`, net.py:607-622) simply appear several times among the inputs; autograd
+    sums their gradients."""
+
+    @staticmethod
+    def forward(ctx, P, transposes, *flat):
+        params = [tuple(flat[4 * k:4 * k + 4]) for k in range(len(flat) // 4)]
+        ctx.P, ctx.transposes = P, tuple(transposes)
+        ctx.save_for_backward(*flat)
+        return tuple(ops.gabor_filter_banks(params, P, transposes))
+
+    @staticmethod
+    def backward(ctx, *dws):
+        flat = ctx.saved_tensors
+        params = [tuple(flat[4 * k:4 * k + 4]) for k in range(len(flat) // 4)]
+        dws = [None if d is None else d.contiguous() for d in dws]
+        grads = ops.gabor_filter_banks_bwd(params, dws, ctx.P, ctx.transposes)
+        out = []
+        for k, g in enumerate(grads):
+            out.extend(g if dws[k] is not None else (None, None, None, None))
+        return (None, None, *out)
+
+
+def filter_banks(modules, transposes):
+    """Filters of several ConvAdjoint2dGabor modules from one launch (and one autograd node)."""
+    flat = []
+    for m in modules:
+        if not m.psi.is_cuda:
+            raise RuntimeError("ConvAdjoint2dGabor: parameters are on the CPU; the filter synthesis kernel runs on "
+                               "the ROCm device only (use .to('cuda'))")
+        flat += [m.alpha, m.a, m.w0, m.psi]
+    return list(_GaborBanks.apply(modules[0].ks, tuple(bool(t) for t in transposes), *flat))
+
+
 def gabor_kernel_cpu(alpha, a, w0, psi, ks, transpose=False):
     """Init-time CPU evaluation of the same formula (gabor.py:7-28,46-51) for the constructor's
     power method; the device path is `cdl_gabor_filters`."""

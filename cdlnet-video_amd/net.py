@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import loop, ops
-from .gabor import ConvAdjoint2dGabor, gabor_kernel_cpu
+from .gabor import ConvAdjoint2dGabor, filter_banks, gabor_kernel_cpu
 from .solvers import gram_operator, power_method
 
 
@@ -443,9 +443,11 @@ class GDLNet(_ISTANet):
         self.order, self.adaptive = order, adaptive
 
     def _filters(self):
-        A = [m.get_filter(transpose=True) for m in self.A]
-        B = [m.get_filter() for m in self.B]
-        return A, B
+        """All 2K banks from one launch and one autograd node (gabor.filter_banks); same values as the per-module
+        `get_filter` calls of the reference (net.py:665-671)."""
+        K = len(self.A)
+        banks = filter_banks(list(self.A) + list(self.B), [True] * K + [False] * K)
+        return banks[:K], banks[K:]
 
     @torch.no_grad()
     def project(self):

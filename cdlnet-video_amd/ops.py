@@ -442,6 +442,43 @@ def gabor_filters_bwd(alpha, a, w0, psi, dw, P, transpose):
     return outs
 
 
+def gabor_filter_banks(params, P, transposes):
+    """All banks of a net in one launch.  params: [(alpha, a, w0, psi)] per bank; returns the list of (M,C,P,P)
+    filters (views of one allocation)."""
+    nb = len(params)
+    params = [tuple(_dev(v, n) for v, n in zip(pr, ("alpha", "a", "w0", "psi"))) for pr in params]
+    order, M, C = params[0][3].shape
+    out = torch.empty((nb, M, C, P, P), device=params[0][3].device, dtype=torch.float32)
+    ws = list(out.unbind(0))
+    flags = (ctypes.c_int * nb)(*[int(bool(t)) for t in transposes])
+    rc = _lib.lib().cdl_gabor_filter_banks(nb, *(_ptr_table([pr[i] for pr in params]) for i in range(4)), flags,
+                                           _ptr_table(ws), order, M, C, P, _stream())
+    _lib.check(rc, "cdl_gabor_filter_banks")
+    return ws
+
+
+def gabor_filter_banks_bwd(params, dws, P, transposes):
+    """Adjoint of gabor_filter_banks in one launch: per bank (dalpha, da, dw0, dpsi) for upstream dws[k] (None: zeros)."""
+    nb = len(params)
+    params = [tuple(_dev(v, n) for v, n in zip(pr, ("alpha", "a", "w0", "psi"))) for pr in params]
+    dws = [None if d is None else _dev(d, "dw") for d in dws]
+    order, M, C = params[0][3].shape
+    nq = order * M * C
+    dev = params[0][3].device
+    blocks = torch.empty((nb, 6 * nq), device=dev, dtype=torch.float32)
+    flags = (ctypes.c_int * nb)(*[int(bool(t)) for t in transposes])
+    dwtab = (ctypes.c_void_p * nb)(*[None if d is None else d.data_ptr() for d in dws])
+    rc = _lib.lib().cdl_gabor_filter_banks_bwd(nb, *(_ptr_table([pr[i] for pr in params]) for i in range(4)), flags,
+                                               dwtab, _ptr_table(list(blocks.unbind(0))), order, M, C, P, _stream())
+    _lib.check(rc, "cdl_gabor_filter_banks_bwd")
+    outs = []
+    for k, pr in enumerate(params):
+        b = blocks[k]
+        outs.append((b[:nq].view_as(pr[0]), b[nq:3 * nq].view_as(pr[1]), b[3 * nq:5 * nq].view_as(pr[2]),
+                     b[5 * nq:].view_as(pr[3])))
+    return outs
+
+
 # ------------------------------------------------------------------------------------------ fused MFMA path
 PRECISION = {"split3": 0, "bf16": 1}
 # layouts of the fat tensors that stay inside a fused sweep (include/cdlnet_hip.h, CDL_LAY_*): "nchw" is the

@@ -242,6 +242,17 @@ int cdl_project_filter_banks(float *const *w, int nbanks, int nfilters, int flen
 int cdl_gabor_filters(const float *alpha, const float *a, const float *w0, const float *psi,
                       float *w /*M,C,P,P*/, int order, int M, int C, int P, int transpose, void *stream);
 
+/* Every bank of a net in ONE launch (GDLNet.forward re-synthesises its 2K banks per call, net.py:659-675):
+ * bank k reads alpha[k], a[k], w0[k], psi[k] (aliased pointers are fine: shared parameters, net.py:607-622), writes
+ * w[k]; transpose[k] != 0 selects the analysis filter.  _bwd: grads[k] receives the block
+ * [dalpha (order*M*C) | da (2*order*M*C) | dw0 (2*order*M*C) | dpsi (order*M*C)] for upstream dw[k] (zeros when
+ * dw[k] is NULL); the caller sums the blocks of aliased parameters. */
+int cdl_gabor_filter_banks(int nbanks, const float *const *alpha, const float *const *a, const float *const *w0,
+                           const float *const *psi, const int *transpose, float *const *w, int order, int M, int C,
+                           int P, void *stream);
+int cdl_gabor_filter_banks_bwd(int nbanks, const float *const *alpha, const float *const *a, const float *const *w0,
+                               const float *const *psi, const int *transpose, const float *const *dw,
+                               float *const *grads, int order, int M, int C, int P, void *stream);
 /* Backward of cdl_gabor_filters: given dw (M,C,P,P) writes dalpha, da, dw0, dpsi (overwritten). */
 int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, const float *psi,
                           const float *dw, float *dalpha, float *da, float *dw0, float *dpsi,

@@ -11,7 +11,7 @@ SHAPES = [
     (1, 1, 48, (8, 16, 64), (5, 5, 5), False),        # cfg3's operator, exactly one tile per depth
     (2, 1, 48, (5, 21, 70), (5, 5, 5), False),        # ragged tiles, depth 5 = Pd
     (1, 3, 64, (30, 70), (7, 7), True),               # cfg4's operator (JDD): C = 3 + mask, 2-D
-    (2, 1, 20, (3, 17, 33), (3, 3, 3), False),        # P = 3, M not a multiple of 16
+    (2, 1, 24, (3, 17, 33), (3, 3, 3), False),        # P = 3, M not a multiple of 16
     (1, 1, 8, (40, 72), (5, 5), False),               # small M, 2-D, one group
     (1, 1, 64, (4, 16, 64), (3, 7, 7), True),         # Pd = 3 with 7 x 7 planes
 ]

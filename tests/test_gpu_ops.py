@@ -237,6 +237,34 @@ def test_golden_gabor_filters(golden):
             check(f"golden gabor filter {bank}.{k}", got, g["filt"][f"{bank}.{k}"], 1e-5)
 
 
+def test_batched_gabor_banks_equal_per_bank_calls():
+    """cdl_gabor_filter_banks(+_bwd): every bank of a net from one launch -- bit-identical to the per-bank entry
+    points, with a missing upstream gradient giving zeros and ALIASED parameters (GDLNet `shared`) summed by autograd."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd.gabor import ConvAdjoint2dGabor, filter_banks
+    o = ops()
+    torch.manual_seed(3)
+    mods = [ConvAdjoint2dGabor(6, 1, 7, stride=1, order=2).cuda() for _ in range(5)]
+    mods[3].psi, mods[3].a = mods[0].psi, mods[0].a                     # parameter sharing by aliasing
+    tr = [True, True, False, True, False]
+    banks = filter_banks(mods, tr)
+    for m, t, w in zip(mods, tr, banks):
+        assert torch.equal(w, o.gabor_filters(m.alpha, m.a, m.w0, m.psi, 7, t))
+    ups = [torch.randn_like(w) for w in banks]
+    loss = sum((w * u).sum() for k, (w, u) in enumerate(zip(banks, ups)) if k != 2)     # bank 2 gets no gradient
+    loss.backward()
+    per = [o.gabor_filters_bwd(m.alpha, m.a, m.w0, m.psi, u, 7, t) for m, t, u in zip(mods, tr, ups)]
+    for k, m in enumerate(mods):
+        if k == 2:
+            assert m.alpha.grad is None or float(m.alpha.grad.abs().max()) == 0.0
+            continue
+        check(f"batched gabor dalpha[{k}]", m.alpha.grad, per[k][0], 1e-6)
+        check(f"batched gabor dw0[{k}]", m.w0.grad, per[k][2], 1e-6)
+    check("batched gabor dpsi (aliased 0+3)", mods[0].psi.grad, per[0][3] + per[3][3], 1e-6)
+    check("batched gabor da (aliased 0+3)", mods[0].a.grad, per[0][1] + per[3][1], 1e-6)
+    check("batched gabor dpsi[1]", mods[1].psi.grad, per[1][3], 1e-6)
+
+
 def test_bad_arguments_fail_loudly():
     import cdlnet_video_amd as cva
     o = cva.ops
