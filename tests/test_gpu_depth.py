@@ -187,3 +187,31 @@ def test_reference_fixtures_run_on_the_fused_kernels():
         assert cva.ops.fused_supported(geom), name
         assert g["grad_cond"] < 2e-6          # the reference's own fp32-vs-fp64 gradient agreement
     assert cva.loop.BACKEND == "auto"
+
+
+def test_cfg2_full_batch_64x256x256():
+    """configs[1] at its FULL size (CDLNet K=30 M=64 P=7, 64 x 1 x 256 x 256) through the fused sweep: samples are
+    independent units of the path, so (i) the batched result equals single-sample runs bit for bit, (ii) those
+    samples match the CPU oracle to 1e-5 with PSNR equal to 2 dp, (iii) everything is finite and denoising gains PSNR."""
+    import cdlnet_video_amd as cva
+    torch.manual_seed(1)
+    K, M, P = 30, 64, 7
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x8 = cva.utils.synthetic_clip((8, 1, 256, 256), seed=0)
+    x = x8.repeat(8, 1, 1, 1)
+    y, sig = cva.awgn(x, (20, 30), torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        xhat, z = net(y.cuda(), sig.cuda())
+        for n in (0, 37, 63):
+            xn, zn = net(y[n:n + 1].cuda(), sig[n:n + 1].cuda())
+            assert torch.equal(xn, xhat[n:n + 1]) and torch.equal(zn, z[n:n + 1]), n
+    assert torch.isfinite(xhat).all()
+    pick = [0, 63]
+    xr, _ = O.ista(sd, y[pick], K=K, P=P, s=1, sigma=sig[pick], adaptive=True)
+    check("cfg2 full batch: samples 0 and 63 vs oracle", xhat[pick], xr, XTOL)
+    p_ref, p_got = O.psnr(x[pick], xr), O.psnr(x[pick], xhat[pick].cpu())
+    log(f"cfg2 full batch 64x256x256: PSNR ref={p_ref:.4f} ours={p_got:.4f} noisy={O.psnr(x[pick], y[pick]):.2f} "
+        f"whole batch {O.psnr(x, xhat.cpu()):.4f}")
+    assert round(p_ref, 2) == round(p_got, 2) and O.psnr(x, xhat.cpu()) > O.psnr(x, y)

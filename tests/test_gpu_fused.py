@@ -447,3 +447,21 @@ def test_bf16_code_storage_keeps_psnr_to_2dp():
         f"the ST supports)")
     assert round(p_ref, 2) == round(p_got, 2)
     assert err < 5e-3 and cos > 0.99
+
+
+def test_assemble_vector_form_is_bit_identical(hip_env):
+    """k_assemble_v4 (batches, W % 4 == 0: 4 pixels x 2 rows per thread, 16-byte thin accesses) against the scalar form
+    (CDL_FUSED_DEBUG bit 512 selects it): same sums in the same order."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    N, M, P, H, W = 16, 32, 7, 256, 256
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    geom = o.Geometry.make(N, 1, M, (H, W), (P, P), (3, 3), 1)
+    patches = torch.randn(o.fused_patches(geom, "cuda").shape, device="cuda", generator=gen)
+    yp = torch.randn(N, 1, H, W, device="cuda", generator=gen)
+    mask = (torch.rand(N, 1, H, W, device="cuda", generator=gen) < 0.5).float()
+    outs = []
+    for dbg in ("0", "512"):
+        hip_env("CDL_FUSED_DEBUG", dbg)
+        outs.append((o.fused_assemble(geom, patches, mask, yp, 1.0), o.fused_assemble(geom, patches, None, None, -1.0)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

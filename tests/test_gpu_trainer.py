@@ -1,0 +1,70 @@
+"""The reference's epoch driver (train.py:35-158, restated in cdlnet_video_amd.train.fit) around REAL nets: every
+forward / backward of the run goes through the HIP kernels (tests/test_trainer_cpu.py covers the control flow with a
+CPU stand-in module)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaders(shape, n_train, seed):
+    import cdlnet_video_amd as cva
+    mk = lambda n, s: [cva.utils.synthetic_clip(shape, seed=s + i).cuda() for i in range(n)]
+    return {"train": mk(n_train, seed), "val": mk(1, seed + 50), "test": mk(1, seed + 60)}
+
+
+def test_fit_trains_a_cdlnet_on_the_gpu(tmp_path):
+    """2-D net on the fused MFMA path: 3 epochs of train / val / test, PSNR logs, checkpoint rotation; the training
+    PSNR improves and a reloaded checkpoint reproduces the network bit for bit."""
+    import cdlnet_video_amd as cva
+    torch.manual_seed(0)
+    net = cva.CDLNet(K=4, M=32, P=5, s=1, C=1, t0=5e-3, adaptive=True, init=True).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.9)
+    loaders = _loaders((4, 1, 40, 72), 4, 0)
+    hist = cva.fit(net, opt, loaders, sched=sched, epochs=3, device=torch.device("cuda"), save_dir=str(tmp_path),
+                   clip_grad=5e-2, noise_std=(20, 30), val_freq=1, save_freq=1, verbose=False, log=lambda *_: None)
+    train = [v for e, p, v in hist if p == "train"]
+    assert len(train) == 3 and all(torch.isfinite(torch.tensor(train)))
+    assert train[-1] > train[0], train                         # it learns
+    assert [p for e, p, _ in hist if e == 3] == ["train", "val", "test"]
+    assert set(os.listdir(tmp_path)) >= {"0.ckpt", "net.ckpt", "train.txt", "val.txt", "test.txt"}
+    again = cva.CDLNet(K=4, M=32, P=5, s=1, C=1, t0=5e-3, adaptive=True, init=False)
+    cva.load_ckpt(os.path.join(str(tmp_path), "net.ckpt"), again)
+    again = again.cuda()
+    y = loaders["val"][0]
+    with torch.no_grad():
+        a, _ = net(y, 25.0)
+        b, _ = again(y, 25.0)
+    assert torch.equal(a, b)
+    assert float(net.t.min()) >= 0.0                            # project() ran after every step (train.py:102)
+
+
+def test_fit_backtracks_a_diverging_video_net(tmp_path):
+    """3-D net on the fused generic path: after the epoch-1 checkpoint a filter bank is blown up by 1e3, so epoch 2
+    collapses (PSNR far below the best, or nan / inf); fit must reload the checkpoint, scale the learning rate by
+    0.8, repeat the epoch with the restored weights and finish."""
+    import cdlnet_video_amd as cva
+    torch.manual_seed(1)
+    net = cva.CDLNetVideo(K=2, M=16, P=[3, 5, 5], s=1, C=1, t0=5e-3, adaptive=True, depth=4, init=True).cuda()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    loaders = _loaders((1, 1, 4, 24, 40), 3, 20)
+    logs, fired = [], []
+
+    def epoch_fun(epoch):                                       # runs right after net.ckpt of that epoch is written
+        if epoch == 1 and not fired:
+            fired.append(1)
+            with torch.no_grad():
+                net.B[0].weight.mul_(1e3)
+
+    hist = cva.fit(net, opt, loaders, epochs=3, device=torch.device("cuda"), save_dir=str(tmp_path), clip_grad=1,
+                   noise_std=25, val_freq=10, save_freq=1, verbose=False, backtrack_thresh=1, epoch_fun=epoch_fun,
+                   log=logs.append)
+    assert [e for e, p, _ in hist if p == "train"] == [1, 2, 2, 3]          # epoch 2 repeated once
+    assert sum("Backtracking" in str(m) for m in logs) == 1
+    assert open(tmp_path / "backtrack.txt").read().split() == ["2"]
+    assert abs(cva.train.getlr(opt)[0] - 0.8e-3) < 1e-12
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    assert float(net.B[0].weight.abs().max()) < 10.0              # the blown-up bank was replaced by the checkpoint's
