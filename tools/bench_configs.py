@@ -27,6 +27,7 @@ CONFIGS = {
     "cfg1": ("2d", dict(K=10, M=32, P=5, s=1, C=1), (1, 1, 128, 128), 25.0, False, 1),
     "cfg1-b10": ("2d", dict(K=10, M=32, P=5, s=1, C=1), (10, 1, 128, 128), 25.0, False, 2),
     "cfg2": ("2d", dict(K=30, M=64, P=7, s=1, C=1), (64, 1, 256, 256), 25.0, False, 1),
+    "cfg2-b16": ("2d", dict(K=30, M=64, P=7, s=1, C=1), (16, 1, 256, 256), 25.0, False, 1),   # cfg5's batch: per-pixel comparison
     "s2030-arch": ("2d", dict(K=30, M=169, P=7, s=2, C=1), (64, 1, 256, 256), 25.0, False, 1),
     "cfg3": ("3d", dict(K=20, M=48, P=[5, 5, 5], s=1, C=1), (8, 1, 8, 128, 128), 25.0, False, 1),
     "cfg4": ("2d", dict(K=42, M=64, P=7, s=1, C=3), (8, 3, 256, 256), (1.0, 20.0), True, 1),
