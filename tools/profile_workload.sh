@@ -13,7 +13,7 @@ script=$root/$1; shift
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- python3 "$script" "$@" > "$out/trace.log" 2>&1
 echo "[$tag] kernel trace done"
 i=0
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -o p -- python3 "$script" "$@" > "$out/pmc$i.log" 2>&1
   echo "[$tag] pmc pass $i done"
   i=$((i+1))
