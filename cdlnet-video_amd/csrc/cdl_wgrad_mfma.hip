@@ -94,7 +94,79 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 for (int q = 0; q < CT; ++q)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) acc[gi][R][q][v] = 0.0f;
-        if (active) {
+        // Fast path (rows are whole 32-byte segments: Wz % 8 == 0, 16-byte aligned bases): the fat operand of k-step
+        // ks+1 is loaded -- branch-free, at a clamped address -- while k-step ks is converted, gathered and multiplied.
+        // The first version issued the loads of a k-step and consumed them at once: every k-step exposed a global
+        // load latency (62 % of the wave cycles were waits, 20 % matrix-core utilisation).
+        // (ungated operands only -- the sweeps gate their gradients in place upstream; a gate would double the
+        //  prefetch registers and spill)
+        constexpr bool PREFETCH = NG * RT * CT * 16 <= 160;   // 32 prefetch registers next to the accumulators
+        const bool fast = PREFETCH && vec4 && (Wz & 7) == 0 && gate == nullptr;
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        f32x4 fraw[2][CT][2];                               // [ping-pong][channel tile][half segment]
+        auto fat_issue = [&](int ks, f32x4 (&fr)[CT][2]) {
+            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
+            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
+#pragma unroll
+            for (int q = 0; q < CT; ++q) {
+                const int m = 32 * (CT * cg + q) + l32;
+                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
+                const size_t idx = ok ? fbase + (size_t)m * slab + (size_t)cy * Wz + cx0 : fbase;
+                fr[q][0] = *reinterpret_cast<const f32x4 *>(F + idx);
+                fr[q][1] = *reinterpret_cast<const f32x4 *>(F + idx + 4);
+            }
+        };
+        auto kstep = [&](int ks, const f32x4 (&fr)[CT][2]) {
+            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
+            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
+            bf16x8 bh[CT], bl[CT];
+#pragma unroll
+            for (int q = 0; q < CT; ++q) {
+                const int m = 32 * (CT * cg + q) + l32;
+                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = ok ? fr[q][i >> 2][i & 3] : 0.0f;
+                    const __bf16 hh = (__bf16)v;
+                    bh[q][i] = hh;
+                    bl[q][i] = (__bf16)(v - (float)hh);
+                }
+            }
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                for (int R = 0; R < RT; ++R) {
+                    const int o = gi * XE + (zy * SW + tki[R]) * XW + zx0 * SW + tkj[R];
+                    bf16x8 ah, al;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        ah[i] = xh[o + i * SW];
+                        al[i] = xl[o + i * SW];
+                    }
+#pragma unroll
+                    for (int q = 0; q < CT; ++q) {
+                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[gi][R][q], 0, 0, 0);
+                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[gi][R][q], 0, 0, 0);
+                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[gi][R][q], 0, 0, 0);
+                    }
+                }
+        };
+        bool pipelined = false;
+        if constexpr (PREFETCH) {
+            if (active && fast) {
+                pipelined = true;
+                const int k0 = pp * kpw, k1 = (pp + 1) * kpw;   // kpw is even (a power of two >= 16)
+                fat_issue(k0, fraw[0]);
+#pragma unroll 1
+                for (int ks = k0; ks < k1; ks += 2) {
+                    fat_issue(ks + 1, fraw[1]);
+                    kstep(ks, fraw[0]);
+                    if (ks + 2 < k1) fat_issue(ks + 2, fraw[0]);
+                    kstep(ks + 1, fraw[1]);
+                }
+            }
+        }
+        if (active && !pipelined) {
 #pragma unroll 1
             for (int ks = pp * kpw; ks < (pp + 1) * kpw; ++ks) {
                 const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;       // tile-local pixels zx0 .. zx0+7 of row zy

@@ -52,3 +52,32 @@ def test_two_ranks_stay_identical_and_match_the_global_batch_gradient(tmp_path):
     for n_, p in net.named_parameters():
         if p.grad is not None:
             check(f"DP world-2 averaged gradient vs global batch: {n_}", res["first_grads"][n_], p.grad, 2e-5)
+
+
+def test_net_on_a_non_current_device():
+    """a module moved to cuda:1 without torch.cuda.set_device(1) must run on cuda:1's stream with
+    cuda:1's launch attributes (ops.py makes the tensors' device current per call; the library keeps its launch
+    bookkeeping per device).  Needs two visible GPUs; the one-GPU boxes skip it."""
+    import cdlnet_video_amd as cva
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    torch.manual_seed(0)
+    net = cva.CDLNet(K=3, M=32, P=7, s=1, C=1, t0=5e-3, adaptive=True, init=False)
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if n_ not in ("t", "g"):
+                p.mul_(0.05)
+    y = torch.rand(2, 1, 40, 72)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        assert torch.cuda.current_device() == 0
+        m = net.to(dev)
+        xhat, z = m(y.to(dev), 25.0)
+        xhat.square().mean().backward()
+        outs.append((xhat.detach().cpu(), z.detach().cpu(), m.A[1].weight.grad.detach().cpu().clone()))
+        for p in m.parameters():
+            p.grad = None
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):                      # tensors of one call on two devices
+        net.to("cuda:1")(y.to("cuda:0"), 25.0)
