@@ -633,6 +633,53 @@ __global__ __launch_bounds__(256) void k_assemble_g(const float *__restrict__ pa
     out[i] = v;
 }
 
+// Batch form (W % 4 == 0): a thread owns 4 consecutive pixels (16-byte thin accesses); the covering tiles of a
+// 4-pixel group differ only when the group straddles a tile border, so each pixel still sums its own patches in the
+// same (kd, tile row, tile column) order as k_assemble_g: bit-identical.
+template <int P>
+__global__ __launch_bounds__(256) void k_assemble_g4(const float *__restrict__ patches, const float *__restrict__ mask,
+                                                     const float *__restrict__ sub, float alpha, float *__restrict__ out,
+                                                     int N, int C, int D, int H, int W, int Pd, int tilesX, int tilesY)
+{
+    constexpr int HALO = P / 2, PY = TH + P - 1, PX = TW + P - 1;
+    const int X0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X0 >= W || Y >= H) return;
+    int r = blockIdx.z;
+    const int d = r % D; r /= D;
+    const int c = r % C, n = r / C;
+    const int G = C * Pd;
+    const int ay = Y + HALO;
+    const int ty_hi = min(tilesY - 1, ay / TH), ty_lo = max(0, (ay - PY + TH) / TH);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kd = 0; kd < Pd; ++kd) {
+        const int zd = d + Pd / 2 - kd;
+        if (zd < 0 || zd >= D) continue;
+        const int g = c * Pd + kd;
+        const size_t plane = ((size_t)n * D + zd) * tilesY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ax = X0 + e + HALO;
+            const int tx_hi = min(tilesX - 1, ax / TW), tx_lo = max(0, (ax - PX + TW) / TW);
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    const size_t tile = (plane + ty) * tilesX + tx;
+                    acc[e] += patches[((tile * G + g) * PY + (ay - ty * TH)) * PX + (ax - tx * TW)];
+                }
+        }
+    }
+    const size_t i = ((((size_t)n * C + c) * D + d) * H + Y) * W + X0;
+    float4 v = make_float4(alpha * acc[0], alpha * acc[1], alpha * acc[2], alpha * acc[3]);
+    if (mask) {
+        const float4 m = *reinterpret_cast<const float4 *>(mask + i);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+    if (sub) {
+        const float4 sv = *reinterpret_cast<const float4 *>(sub + i);
+        v.x -= sv.x; v.y -= sv.y; v.z -= sv.z; v.w -= sv.w;
+    }
+    *reinterpret_cast<float4 *>(out + i) = v;
+}
+
 // dt0[m] = sum over tiles; dt1[m] = sum_n c[n] * (sum over the tiles of sample n): fixed-order tree (cdl_fused2d.hip)
 __global__ __launch_bounds__(1024) void k_dtau_reduce_g(const float *__restrict__ partial, const float *__restrict__ c,
                                                         float *__restrict__ dt0, float *__restrict__ dt1, int N,
@@ -847,10 +894,17 @@ int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *ma
     Plan pl;
     if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
-    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
+    if ((g->W & 3) == 0 && !(cdl_opts().fused_debug & 512)) {
+        dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
+#define CDL_ASM4(P_) k_assemble_g4<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
+        if (pl.P == 3) CDL_ASM4(3); else if (pl.P == 5) CDL_ASM4(5); else CDL_ASM4(7);
+#undef CDL_ASM4
+    } else {
+        dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
 #define CDL_ASM(P_) k_assemble_g<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
-    if (pl.P == 3) CDL_ASM(3); else if (pl.P == 5) CDL_ASM(5); else CDL_ASM(7);
+        if (pl.P == 3) CDL_ASM(3); else if (pl.P == 5) CDL_ASM(5); else CDL_ASM(7);
 #undef CDL_ASM
+    }
     CDL_LAUNCH_CHECK();
     return 0;
 }

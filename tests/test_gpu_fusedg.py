@@ -154,3 +154,21 @@ def test_fusedg_sweeps_equal_generic_on_same_activations(kind, kw, shape, masked
         assert torch.equal(outs["fusedg"][0][k], outs["again"][0][k]) and torch.equal(outs["fusedg"][1][k], outs["again"][1][k])
     check(f"{tag} dt", outs["fusedg"][2], outs["generic"][2], 5e-5)
     assert torch.equal(outs["fusedg"][2], outs["again"][2])
+
+
+def test_fusedg_assemble_vector_form_is_bit_identical(hip_env):
+    """k_assemble_g4 (W % 4 == 0: 4 pixels per thread, 16-byte thin accesses) against the scalar form (CDL_FUSED_DEBUG
+    bit 512): same sums in the same order."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    for N, C, M, sp, P in ((2, 1, 48, (6, 40, 72), (5, 5, 5)), (1, 3, 64, (36, 132), (7, 7))):
+        g = make_geom(N, C, M, sp, P)
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        patches = torch.randn(o.fusedg_patches(g, "cuda").shape, device="cuda", generator=gen)
+        yp = torch.randn(g.image_shape(), device="cuda", generator=gen)
+        mask = (torch.rand(g.image_shape(), device="cuda", generator=gen) < 0.5).float()
+        outs = []
+        for dbg in ("0", "512"):
+            hip_env("CDL_FUSED_DEBUG", dbg)
+            outs.append((o.fusedg_assemble(g, patches, mask, yp, 1.0), o.fusedg_assemble(g, patches, None, None, -1.0)))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
