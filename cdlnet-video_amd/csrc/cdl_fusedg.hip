@@ -651,20 +651,30 @@ __global__ __launch_bounds__(256) void k_assemble_g4(const float *__restrict__ p
     const int ay = Y + HALO;
     const int ty_hi = min(tilesY - 1, ay / TH), ty_lo = max(0, (ay - PY + TH) / TH);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool has_lo[4];
     for (int kd = 0; kd < Pd; ++kd) {
         const int zd = d + Pd / 2 - kd;
         if (zd < 0 || zd >= D) continue;
         const int g = c * Pd + kd;
         const size_t plane = ((size_t)n * D + zd) * tilesY;
+        // a pixel lies in at most 2 x 2 patches (P - 1 < TH); the row candidates are wave-uniform, the column ones
+        // are loaded side by side (8 independent loads) and added in the scalar form's order
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+            const float *row = patches + ((((plane + ty) * tilesX) * G + g) * PY + (ay - ty * TH)) * PX;
+            float lo[4], hi[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ax = X0 + e + HALO;
-            const int tx_hi = min(tilesX - 1, ax / TW), tx_lo = max(0, (ax - PX + TW) / TW);
-            for (int ty = ty_lo; ty <= ty_hi; ++ty)
-                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
-                    const size_t tile = (plane + ty) * tilesX + tx;
-                    acc[e] += patches[((tile * G + g) * PY + (ay - ty * TH)) * PX + (ax - tx * TW)];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int ax = X0 + e + HALO;
+                const int tx_hi = min(tilesX - 1, ax / TW), tx_lo = max(0, (ax - PX + TW) / TW);
+                hi[e] = row[(size_t)tx_hi * (G * PY * PX) + (ax - tx_hi * TW)];
+                lo[e] = tx_lo < tx_hi ? row[(size_t)tx_lo * (G * PY * PX) + (ax - tx_lo * TW)] : 0.0f;
+                has_lo[e] = tx_lo < tx_hi;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (has_lo[e]) acc[e] += lo[e];
+                acc[e] += hi[e];
+            }
         }
     }
     const size_t i = ((((size_t)n * C + c) * D + d) * H + Y) * W + X0;
