@@ -21,24 +21,50 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int GLX = 64, GLY = 32;          // code-pixel tile of a workgroup
 constexpr int GNT = 512;                   // 8 waves
-constexpr int CT = 2;                      // 32-channel tiles per wave
 constexpr int KSTEPS = GLX * GLY / 16;     // 16-pixel k-steps per tile (4 per code row)
+constexpr int LDS_MAX = 128 * 1024;
+
+// Unit stride: the thin tile is kept as bf16 PAIRS, twice -- plane E holds (x[2c], x[2c+1]), plane O holds
+// (x[2c+1], x[2c+2]) -- so that the 8 consecutive pixels of an im2col row are 4 whole dwords whatever the parity of the
+// tap column (a 16-byte read at 2-byte alignment costs ~8x an aligned one: the first version spent 60-70 % of the
+// launch in the LDS pipe).  A plane is padded to 16 (mod 64) dwords: the E and O reads of one instruction then fall
+// into disjoint banks.
+constexpr int eo_row_dwords(int sw, int pw) { return ((GLX - 1) * sw + pw + 1) / 2; }
+constexpr int eo_plane_dwords(int sw, int ph, int pw)
+{
+    const int d = ((GLY - 1) * sw + ph) * eo_row_dwords(sw, pw);
+    return d + ((16 - d % 64) + 64) % 64;
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned int, v);
+}
 
 // NG = number of (c, kd) groups held at once: the fat operand is loaded and split into bf16 parts ONCE per
 // k-step and multiplied against the thin tiles of all NG groups (their LDS tiles and accumulators live side by
 // side); launches loop over ceil(G / NG) group batches.
-template <int PH, int PW, int SW, int NG>
-__global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F,
+// CT = 32-channel tiles per wave: 2 halves the LDS gathers per fat byte, 1 halves the accumulators (NG*RT*16 of them),
+// which is what lets two workgroups share a CU (<= 128 registers per lane) when NG*RT <= 5.
+template <int PH, int PW, int SW, int NG, int CT>
+__global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 4 : 2)) void k_wgm(cdl_geom g, const float *__restrict__ F,
                                              const float *__restrict__ gate, const float *__restrict__ x,
                                              float *__restrict__ part, int tilesX, int tilesY, int nct, int MP)
 {
     constexpr int T = PH * PW, RT = (T + 31) / 32, TP = RT * 32;
     constexpr int XH = (GLY - 1) * SW + PH, XW = (GLX - 1) * SW + PW;
     constexpr int XE = ((XH * XW + 7) / 8) * 8;            // elements per bf16 plane (16-byte multiple)
+    constexpr bool EO = SW == 1;                           // paired planes (see eo_plane_dwords)
+    constexpr int RD = eo_row_dwords(SW, PW), PD = eo_plane_dwords(SW, PH, PW);
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *xh = reinterpret_cast<__bf16 *>(smem);         // [NG][XE] hi parts of the image rows under the tile
     __bf16 *xl = xh + NG * XE;                             // [NG][XE] lo parts
     float *red = reinterpret_cast<float *>(smem);          // [8 waves][16][64] cross-wave sums (reuses the tiles)
+    const unsigned int *xw = reinterpret_cast<const unsigned int *>(smem);   // [NG][Eh | Oh | El | Ol][PD]
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
     int b = blockIdx.x;
     const int tx = b % tilesX; b /= tilesX;
@@ -58,13 +84,35 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
     const bool vec4 = (Wz & 3) == 0 && ((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(gate)) & 15) == 0;
 
     // tap of this lane's A rows (clamped into the plane for the padding rows: their outputs are never read)
-    int tki[RT], tkj[RT];
+    int tki[RT], tkj[RT], teo[RT];
 #pragma unroll
     for (int R = 0; R < RT; ++R) {
         const int t = min(32 * R + l32, T - 1);
         tki[R] = t / PW;
         tkj[R] = t % PW;
+        teo[R] = (tkj[R] & 1) * PD + tki[R] * RD + (tkj[R] >> 1);
     }
+    // im2col row of tap tile R of group gi for the 8 pixels zx0 .. zx0+7 of code row zy
+    auto gather = [&](int gi, int R, int zy, int zx0, bf16x8 &ah, bf16x8 &al) {
+        if constexpr (EO) {
+            const int o = gi * 4 * PD + teo[R] + zy * RD + (zx0 >> 1);
+            u32x4 a, b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = xw[o + i];
+                b[i] = xw[o + 2 * PD + i];
+            }
+            ah = __builtin_bit_cast(bf16x8, a);
+            al = __builtin_bit_cast(bf16x8, b);
+        } else {
+            const int o = gi * XE + (zy * SW + tki[R]) * XW + zx0 * SW + tkj[R];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ah[i] = xh[o + i * SW];
+                al[i] = xl[o + i * SW];
+            }
+        }
+    };
 
     for (int g0 = 0; g0 < G; g0 += NG) {
         __syncthreads();                                   // previous batch's reduction has read the buffer
@@ -75,13 +123,34 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             const int d = zd * g.sd - g.pd + kd;
             const bool dok = grp < G && d >= 0 && d < g.D;  // uniform; a plane outside the image is a zero tile
             const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
-            for (int i = threadIdx.x; i < XH * XW; i += GNT) {
-                const int col = i % XW, row = i / XW;
-                const int yy = ybase + row, xx = xbase + col;
-                const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
-                const __bf16 hh = (__bf16)v;
-                xh[gi * XE + i] = hh;
-                xl[gi * XE + i] = (__bf16)(v - (float)hh);
+            if constexpr (EO) {
+                unsigned int *dstw = reinterpret_cast<unsigned int *>(smem) + gi * 4 * PD;
+                for (int i = threadIdx.x; i < XH * RD; i += GNT) {
+                    const int cp = i % RD, row = i / RD;
+                    const int yy = ybase + row, xx = xbase + 2 * cp;
+                    const bool rok = dok && yy >= 0 && yy < g.H;
+                    float v[3], hi[3], lo[3];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const bool ok = rok && xx + e >= 0 && xx + e < g.W && 2 * cp + e < XW;
+                        v[e] = ok ? xplane[(size_t)(ok ? yy : 0) * g.W + (ok ? xx + e : 0)] : 0.0f;
+                        hi[e] = (float)(__bf16)v[e];
+                        lo[e] = v[e] - hi[e];
+                    }
+                    dstw[i] = pack_bf16(hi[0], hi[1]);
+                    dstw[PD + i] = pack_bf16(hi[1], hi[2]);
+                    dstw[2 * PD + i] = pack_bf16(lo[0], lo[1]);
+                    dstw[3 * PD + i] = pack_bf16(lo[1], lo[2]);
+                }
+            } else {
+                for (int i = threadIdx.x; i < XH * XW; i += GNT) {
+                    const int col = i % XW, row = i / XW;
+                    const int yy = ybase + row, xx = xbase + col;
+                    const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
+                    const __bf16 hh = (__bf16)v;
+                    xh[gi * XE + i] = hh;
+                    xl[gi * XE + i] = (__bf16)(v - (float)hh);
+                }
             }
         }
         __syncthreads();
@@ -136,13 +205,8 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
                 for (int R = 0; R < RT; ++R) {
-                    const int o = gi * XE + (zy * SW + tki[R]) * XW + zx0 * SW + tkj[R];
                     bf16x8 ah, al;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        ah[i] = xh[o + i * SW];
-                        al[i] = xl[o + i * SW];
-                    }
+                    gather(gi, R, zy, zx0, ah, al);
 #pragma unroll
                     for (int q = 0; q < CT; ++q) {
                         acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[gi][R][q], 0, 0, 0);
@@ -213,13 +277,8 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
                     for (int R = 0; R < RT; ++R) {
-                        const int o = gi * XE + (zy * SW + tki[R]) * XW + zx0 * SW + tkj[R];
                         bf16x8 ah, al;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            ah[i] = xh[o + i * SW];
-                            al[i] = xl[o + i * SW];
-                        }
+                        gather(gi, R, zy, zx0, ah, al);
 #pragma unroll
                         for (int q = 0; q < CT; ++q) {
                             acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[gi][R][q], 0, 0, 0);
@@ -258,24 +317,27 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
 }
 
 // dw[m][grp][tap] = alpha * sum over the tiles of part[tile][grp][tap][m]; 16 outputs x 16 strided partial
-// sums per workgroup, combined in a fixed order
+// sums per workgroup, combined in a fixed order.  The 16 outputs of a workgroup are 16 consecutive channels of one
+// (grp, tap): every partial read is one 64-byte segment (with consecutive taps per workgroup the same reads were
+// 256 bytes apart and fetched 4x the bytes).
 __global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part, float *__restrict__ dw, float alpha,
                                                   int nparts, int G, int M, int T, int TP, int MP)
 {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, ps = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + o, total = M * G * T;
+    const int mblocks = (M + 15) / 16;
+    const int m = (blockIdx.x % mblocks) * 16 + o, r = blockIdx.x / mblocks;
+    const int tap = r % T, grp = r / T;
+    const int i = (m * G + grp) * T + tap;
+    const bool valid = m < M;
     float s = 0.0f;
-    if (i < total) {
-        const int tap = i % T;
-        const int r = i / T;
-        const int grp = r % G, m = r / G;
+    if (valid) {
         const size_t off = ((size_t)grp * TP + tap) * MP + m, stride = (size_t)G * TP * MP;
         for (int t = ps; t < nparts; t += 16) s += part[(size_t)t * stride + off];
     }
     red[ps][o] = s;
     __syncthreads();
-    if (ps == 0 && i < total) {
+    if (ps == 0 && valid) {
         float v = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[k][o];
@@ -284,7 +346,7 @@ __global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part
 }
 
 struct Plan {
-    int tilesX, tilesY, nct, npx, MP, TP, ng;
+    int tilesX, tilesY, nct, npx, MP, TP, ng, ct;
     size_t tiles, part_floats, lds;
 };
 
@@ -295,6 +357,8 @@ bool plan_for(const cdl_geom *g, Plan *p)
     if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     const int MT = (g->M + 31) / 32;
+    const int CT = MT == 1 ? 1 : 2;                       // (one tile per wave for M = 64 doubles the LDS gathers: slower)   // one channel tile per wave when the waves divide evenly
+    p->ct = CT;
     p->nct = (MT + CT - 1) / CT;
     if (p->nct > 8) return false;                          // M <= 512
     p->npx = 8 / p->nct;
@@ -308,25 +372,34 @@ bool plan_for(const cdl_geom *g, Plan *p)
     const size_t XH = (size_t)(GLY - 1) * g->sh + g->Ph, XW = (size_t)(GLX - 1) * g->sw + g->Pw;
     p->ng = 1;                                             // groups held at once: registers (NG*RT*CT*16 <= 192) and LDS permitting
     const int G = g->C * g->Pd, RT = p->TP / 32;
-    const size_t plane = ((XH * XW + 7) / 8) * 8 * 2 * 2;   // hi + lo bf16 planes of one group
-    if (G >= 5 && RT == 1 && 5 * plane <= 96 * 1024) p->ng = 5;
-    else if (G >= 3 && RT <= 2 && 3 * plane <= 96 * 1024) p->ng = 3;
+    const size_t plane = g->sw == 1 ? (size_t)eo_plane_dwords(1, g->Ph, g->Pw) * 4 * 4    // E/O x hi/lo dword planes
+                                    : ((XH * XW + 7) / 8) * 8 * 2 * 2;                    // hi + lo bf16 planes of one group
+    if (G >= 5 && RT == 1 && 5 * plane <= LDS_MAX) p->ng = 5;
+    else if (G >= 3 && RT <= 2 && 3 * plane <= LDS_MAX) p->ng = 3;
     p->lds = p->ng * plane;
     if (p->lds < 8 * 16 * 64 * 4) p->lds = 8 * 16 * 64 * 4;  // the cross-wave reduction buffer reuses it
-    if (p->lds > 96 * 1024) return false;
+    if (p->lds > LDS_MAX) return false;
     if (p->tiles < 64 || p->tiles >= ((size_t)1 << 31)) return false;   // too few workgroups: the VALU kernels do better
     if (p->part_floats > ((size_t)1 << 27)) return false;               // 512 MiB of partials: not worth it
     return true;
+}
+
+template <int PH, int PW, int SW, int NG, int CT>
+int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
+              hipStream_t st)
+{
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
+    k_wgm<PH, PW, SW, NG, CT><<<(unsigned)p.tiles, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP);
+    CDL_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int PH, int PW, int SW, int NG>
 int launch_ng(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
               hipStream_t st)
 {
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG>, 96 * 1024)) return rc;
-    k_wgm<PH, PW, SW, NG><<<(unsigned)p.tiles, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP);
-    CDL_LAUNCH_CHECK();
-    return 0;
+    return p.ct == 1 ? launch_ct<PH, PW, SW, NG, 1>(g, p, F, gate, x, ws, st)
+                     : launch_ct<PH, PW, SW, NG, 2>(g, p, F, gate, x, ws, st);
 }
 
 template <int PH, int PW, int SW>
@@ -339,8 +412,8 @@ int launch(const cdl_geom *g, const Plan &p, const float *F, const float *gate, 
     else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st);
     else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st);
     if (rc) return rc;
-    const int G = g->C * g->Pd, T = g->Ph * g->Pw, total = g->M * G * T;
-    k_wgm_fold<<<(total + 15) / 16, 256, 0, st>>>(ws, dw, alpha, (int)p.tiles, G, g->M, T, p.TP, p.MP);
+    const int G = g->C * g->Pd, T = g->Ph * g->Pw;
+    k_wgm_fold<<<G * T * ((g->M + 15) / 16), 256, 0, st>>>(ws, dw, alpha, (int)p.tiles, G, g->M, T, p.TP, p.MP);
     CDL_LAUNCH_CHECK();
     return 0;
 }

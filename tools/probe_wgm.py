@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""GPU-box: the matrix-core filter-gradient launch (cdl_wgrad_mfma.hip) alone at a BASELINE shape, for rocprofv3.
+
+    python tools/probe_wgm.py cfg3|cfg4 [launches]
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                                    # noqa: E402
+import cdlnet_video_amd as cva                  # noqa: E402
+
+o = cva.ops
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+if cfg == "cfg3":
+    N, C, M, sp, P = 8, 1, 48, (8, 128, 128), (5, 5, 5)
+else:
+    N, C, M, sp, P = 8, 3, 64, (256, 256), (7, 7)
+g = o.Geometry.make(N, C, M, sp, P, tuple(p // 2 for p in P), 1)
+gen = torch.Generator(device="cuda").manual_seed(0)
+r = torch.randn(g.image_shape(), device="cuda", generator=gen)
+z = torch.randn(g.code_shape(), device="cuda", generator=gen) * (torch.rand(g.code_shape(), device="cuda", generator=gen) < 0.2)
+for _ in range(3):
+    dw = o.wgrad(g, z, r, -1.0)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(reps):
+    dw = o.wgrad(g, z, r, -1.0)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / reps
+fat = z.numel() * 4
+print(json.dumps({"shape": cfg, "wgrad_ms": round(ms, 4), "GBps": round(fat / ms / 1e6, 1), "frac_of_8TBps": round(fat / ms / 8e9, 3)}))
