@@ -51,9 +51,10 @@ __device__ __forceinline__ unsigned int pack_bf16(float a, float b)
 // CT = 32-channel tiles per wave: 2 halves the LDS gathers per fat byte, 1 halves the accumulators (NG*RT*16 of them),
 // which is what lets two workgroups share a CU (<= 128 registers per lane) when NG*RT <= 5.
 template <int PH, int PW, int SW, int NG, int CT>
-__global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 4 : 2)) void k_wgm(cdl_geom g, const float *__restrict__ F,
+__global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F,
                                              const float *__restrict__ gate, const float *__restrict__ x,
-                                             float *__restrict__ part, int tilesX, int tilesY, int nct, int MP)
+                                             float *__restrict__ part, int tilesX, int tilesY, int nct, int MP, int dbg,
+                                             int ntiles, int tpw)
 {
     constexpr int T = PH * PW, RT = (T + 31) / 32, TP = RT * 32;
     constexpr int XH = (GLY - 1) * SW + PH, XW = (GLX - 1) * SW + PW;
@@ -63,13 +64,12 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *xh = reinterpret_cast<__bf16 *>(smem);         // [NG][XE] hi parts of the image rows under the tile
     __bf16 *xl = xh + NG * XE;                             // [NG][XE] lo parts
-    float *red = reinterpret_cast<float *>(smem);          // [8 waves][16][64] cross-wave sums (reuses the tiles)
     const unsigned int *xw = reinterpret_cast<const unsigned int *>(smem);   // [NG][Eh | Oh | El | Ol][PD]
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
-    int b = blockIdx.x;
-    const int tx = b % tilesX; b /= tilesX;
-    const int ty = b % tilesY; b /= tilesY;
-    const int zd = b % Dz, n = b / Dz;
+    // a workgroup accumulates tpw consecutive tiles (same image / depth plane mostly) before it reduces: one
+    // cross-wave sum and one partial bank per workgroup
+    int tx = 0, ty = 0, zd = 0, n = 0, ybase = 0, xbase = 0;
+    size_t fbase = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l32 = lane & 31, h = lane >> 5;
     const int G = g.C * g.Pd;
@@ -78,8 +78,6 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
     const bool active = pp < npx;                          // 8 % nct waves idle when nct does not divide 8
     const int kpw = KSTEPS / npx;                          // k-steps per wave
     const size_t slab = (size_t)Dz * Hz * Wz;
-    const size_t fbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
-    const int ybase = ty * GLY * SW - g.ph, xbase = tx * GLX * SW - g.pw;
     // 16-byte loads of the fat operand need rows that start on 16-byte boundaries (the base pointers do)
     const bool vec4 = (Wz & 3) == 0 && ((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(gate)) & 15) == 0;
 
@@ -114,35 +112,90 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
         }
     };
 
-    for (int g0 = 0; g0 < G; g0 += NG) {
-        __syncthreads();                                   // previous batch's reduction has read the buffer
-#pragma unroll 1
-        for (int gi = 0; gi < NG; ++gi) {
-            const int grp = g0 + gi;
-            const int kd = grp % g.Pd, c = grp / g.Pd;
-            const int d = zd * g.sd - g.pd + kd;
-            const bool dok = grp < G && d >= 0 && d < g.D;  // uniform; a plane outside the image is a zero tile
-            const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
-            if constexpr (EO) {
-                unsigned int *dstw = reinterpret_cast<unsigned int *>(smem) + gi * 4 * PD;
-                for (int i = threadIdx.x; i < XH * RD; i += GNT) {
-                    const int cp = i % RD, row = i / RD;
-                    const int yy = ybase + row, xx = xbase + 2 * cp;
-                    const bool rok = dok && yy >= 0 && yy < g.H;
-                    float v[3], hi[3], lo[3];
+    // thin-tile staging (unit stride): pair i of a group = dwords (x[2cp], x[2cp+1]) / (x[2cp+1], x[2cp+2]) of tile row
+    // `row`; the loads of two groups are issued before any of them is converted (15 dependent rounds of load -> LDS
+    // write took 12 of the first version's 100 us at cfg3)
+    constexpr int NPAIR = XH * RD, ITG = (NPAIR + GNT - 1) / GNT;
+    auto st_load = [&](int grp, float (&v)[ITG][3]) {
+        const int kd = grp % g.Pd, c = grp / g.Pd;
+        const int d = zd * g.sd - g.pd + kd;
+        const bool dok = grp < G && d >= 0 && d < g.D;      // uniform; a plane outside the image is a zero tile
+        const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        const bool ok = rok && xx + e >= 0 && xx + e < g.W && 2 * cp + e < XW;
-                        v[e] = ok ? xplane[(size_t)(ok ? yy : 0) * g.W + (ok ? xx + e : 0)] : 0.0f;
-                        hi[e] = (float)(__bf16)v[e];
-                        lo[e] = v[e] - hi[e];
-                    }
-                    dstw[i] = pack_bf16(hi[0], hi[1]);
-                    dstw[PD + i] = pack_bf16(hi[1], hi[2]);
-                    dstw[2 * PD + i] = pack_bf16(lo[0], lo[1]);
-                    dstw[3 * PD + i] = pack_bf16(lo[1], lo[2]);
+        for (int it = 0; it < ITG; ++it) {
+            const int i = threadIdx.x + it * GNT;
+            const int cp = i % RD, row = i / RD;
+            const int yy = ybase + row, xx = xbase + 2 * cp;
+            const bool rok = dok && i < NPAIR && yy >= 0 && yy < g.H;
+            const float *prow = xplane + (size_t)min(max(yy, 0), g.H - 1) * g.W;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const bool ok = rok && xx + e >= 0 && xx + e < g.W && 2 * cp + e < XW;
+                const float t = prow[min(max(xx + e, 0), g.W - 1)];
+                v[it][e] = ok ? t : 0.0f;
+            }
+        }
+    };
+    auto st_write = [&](int gi, const float (&v)[ITG][3]) {
+        unsigned int *dstw = reinterpret_cast<unsigned int *>(smem) + gi * 4 * PD;
+#pragma unroll
+        for (int it = 0; it < ITG; ++it) {
+            const int i = threadIdx.x + it * GNT;
+            if (i < NPAIR) {
+                float hi[3], lo[3];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    hi[e] = (float)(__bf16)v[it][e];
+                    lo[e] = v[it][e] - hi[e];
                 }
-            } else {
+                dstw[i] = pack_bf16(hi[0], hi[1]);
+                dstw[PD + i] = pack_bf16(hi[1], hi[2]);
+                dstw[2 * PD + i] = pack_bf16(lo[0], lo[1]);
+                dstw[3 * PD + i] = pack_bf16(lo[1], lo[2]);
+            }
+        }
+    };
+
+    for (int g0 = 0; g0 < G; g0 += NG) {
+        f32x16 acc[NG][RT][CT];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int R = 0; R < RT; ++R)
+#pragma unroll
+                for (int q = 0; q < CT; ++q)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[gi][R][q][v] = 0.0f;
+#pragma unroll 1
+        for (int tl = 0; tl < tpw; ++tl) {
+        int b = blockIdx.x * tpw + tl;
+        if (b >= ntiles) break;                            // uniform
+        tx = b % tilesX; b /= tilesX;
+        ty = b % tilesY; b /= tilesY;
+        zd = b % Dz; n = b / Dz;
+        fbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
+        ybase = ty * GLY * SW - g.ph; xbase = tx * GLX * SW - g.pw;
+        __syncthreads();                                   // previous tile / previous batch's reduction has read the buffer
+        if constexpr (EO) {
+            if (!(dbg & 1024)) {                           // (CDL_FUSED_DEBUG bits 1024 / 2048 / 4096: timing ablations)
+                constexpr int GS = NG * RT * CT * 16 <= 160 ? 2 : 1;   // groups in flight (registers next to acc)
+#pragma unroll
+                for (int gi = 0; gi < NG; gi += GS) {
+                    float va[ITG][3], vb[ITG][3];
+                    st_load(g0 + gi, va);
+                    if (GS == 2 && gi + 1 < NG) st_load(g0 + gi + 1, vb);
+                    st_write(gi, va);
+                    if (GS == 2 && gi + 1 < NG) st_write(gi + 1, vb);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int gi = 0; gi < ((dbg & 1024) ? 0 : NG); ++gi) {
+                const int grp = g0 + gi;
+                const int kd = grp % g.Pd, c = grp / g.Pd;
+                const int d = zd * g.sd - g.pd + kd;
+                const bool dok = grp < G && d >= 0 && d < g.D;  // uniform; a plane outside the image is a zero tile
+                const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
                 for (int i = threadIdx.x; i < XH * XW; i += GNT) {
                     const int col = i % XW, row = i / XW;
                     const int yy = ybase + row, xx = xbase + col;
@@ -154,15 +207,6 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
             }
         }
         __syncthreads();
-        f32x16 acc[NG][RT][CT];
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-            for (int R = 0; R < RT; ++R)
-#pragma unroll
-                for (int q = 0; q < CT; ++q)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[gi][R][q][v] = 0.0f;
         // Fast path (rows are whole 32-byte segments: Wz % 8 == 0, 16-byte aligned bases): the fat operand of k-step
         // ks+1 is loaded -- branch-free, at a clamped address -- while k-step ks is converted, gathered and multiplied.
         // The first version issued the loads of a k-step and consumed them at once: every k-step exposed a global
@@ -217,7 +261,7 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
         };
         bool pipelined = false;
         if constexpr (PREFETCH) {
-            if (active && fast) {
+            if (active && fast && !(dbg & 2048)) {
                 pipelined = true;
                 const int k0 = pp * kpw, k1 = (pp + 1) * kpw;   // kpw is even (a power of two >= 16)
                 fat_issue(k0, fraw[0]);
@@ -230,7 +274,7 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
                 }
             }
         }
-        if (active && !pipelined) {
+        if (active && !pipelined && !(dbg & 2048)) {
 #pragma unroll 1
             for (int ks = pp * kpw; ks < (pp + 1) * kpw; ++ks) {
                 const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;       // tile-local pixels zx0 .. zx0+7 of row zy
@@ -288,30 +332,69 @@ __global__ __launch_bounds__(GNT, (NG * ((PH * PW + 31) / 32) * CT * 16 <= 80 ? 
                     }
             }
         }
-        // ---- sum the pixel parts of every channel group through LDS (fixed order) and write ONE partial bank per
-        //      tile: partial[tile][grp][tap][m]; register v of tile (R, q) is tap 32R + 8(v>>2) + 4h + (v&3) of
-        //      channel 32(CT cg + q) + l32
-#pragma unroll                                             // static accumulator indices (a rolled loop sends acc to scratch)
-        for (int gi = 0; gi < NG; ++gi) {
-            if (g0 + gi >= G) continue;                    // uniform
-            float *dst = part + ((size_t)blockIdx.x * G + g0 + gi) * ((size_t)TP * MP);
+        }   // tiles of this workgroup
+        // ---- sum the pixel parts of every channel group: a binary tree over the waves through LDS (the upper half
+        //      of the parts writes, the lower half adds; 16-byte accesses, as many accumulator tiles per round as the
+        //      buffer holds for 4 writers), then the waves of part 0 write ONE partial bank per tile,
+        //      partial[tile][grp][tap][m]; register v of tile (R, q) is tap 32R + 8(v>>2) + 4h + (v&3) of channel
+        //      32(CT cg + q) + l32.  Fixed order: deterministic.  (The first version made 2 barriers and a strided
+        //      8-term sum per accumulator tile: 25 of the 100 us of a cfg3 launch.)
+        if (!(dbg & 4096)) {
+            constexpr int NT = NG * RT * CT;
+            constexpr int LDS_BYTES = NG * (EO ? 4 * PD * 4 : XE * 4) > 32768 ? NG * (EO ? 4 * PD * 4 : XE * 4) : 32768;
+            constexpr int TPR = LDS_BYTES / (4 * 4096) < NT ? LDS_BYTES / (4 * 4096) : NT;   // tiles per round
+            typedef __attribute__((ext_vector_type(4))) float f32x4;
+            f32x4 *red4 = reinterpret_cast<f32x4 *>(smem);     // [4 writers][TPR][4][64 lanes] x 16 bytes
+            for (int half = npx >> 1; half >= 1; half >>= 1) {
+                const bool writer = active && pp >= half && pp < 2 * half;
+                const bool reader = active && pp < half;
+                const int slot = ((writer ? pp - half : pp) * nct + cg) & 3;
 #pragma unroll
-            for (int R = 0; R < RT; ++R)
-#pragma unroll
-                for (int q = 0; q < CT; ++q) {
+                for (int t0 = 0; t0 < NT; t0 += TPR) {
                     __syncthreads();                       // the tiles (first round) / the previous round are consumed
+                    if (writer) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) red[(wv * 16 + v) * 64 + lane] = acc[gi][R][q][v];
+                        for (int t = t0; t < (t0 + TPR < NT ? t0 + TPR : NT); ++t)
+#pragma unroll
+                            for (int v4 = 0; v4 < 4; ++v4) {
+                                const f32x16 &a = acc[t / (RT * CT)][(t / CT) % RT][t % CT];
+                                red4[((slot * TPR + (t - t0)) * 4 + v4) * 64 + lane] =
+                                    f32x4{a[4 * v4], a[4 * v4 + 1], a[4 * v4 + 2], a[4 * v4 + 3]};
+                            }
+                    }
                     __syncthreads();
-                    for (int o = threadIdx.x; o < nct * 1024; o += GNT) {
-                        const int cgo = o >> 10, e = o & 1023, v = e >> 6, ln = e & 63;
-                        float sum = 0.0f;
-                        for (int p2 = 0; p2 < npx; ++p2) sum += red[((p2 * nct + cgo) * 16 + v) * 64 + ln];
-                        const int tap = 32 * R + 8 * (v >> 2) + 4 * (ln >> 5) + (v & 3);
-                        const int m = 32 * (CT * cgo + q) + (ln & 31);
-                        dst[(size_t)tap * MP + m] = sum;
+                    if (reader) {
+#pragma unroll
+                        for (int t = t0; t < (t0 + TPR < NT ? t0 + TPR : NT); ++t) {
+#pragma unroll
+                            for (int v4 = 0; v4 < 4; ++v4) {
+                                const f32x4 r = red4[((slot * TPR + (t - t0)) * 4 + v4) * 64 + lane];
+                                f32x16 &a = acc[t / (RT * CT)][(t / CT) % RT][t % CT];
+                                a[4 * v4] += r[0]; a[4 * v4 + 1] += r[1]; a[4 * v4 + 2] += r[2]; a[4 * v4 + 3] += r[3];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);     // one tile's 4 reads in flight, not all of them
+                        }
                     }
                 }
+            }
+            if (active && pp == 0) {
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    if (g0 + gi >= G) continue;            // uniform
+                    float *dst = part + ((size_t)blockIdx.x * G + g0 + gi) * ((size_t)TP * MP);
+#pragma unroll
+                    for (int R = 0; R < RT; ++R)
+#pragma unroll
+                        for (int q = 0; q < CT; ++q) {
+                            const int m = 32 * (CT * cg + q) + l32;
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                const int tap = 32 * R + 8 * (v >> 2) + 4 * h + (v & 3);
+                                if (tap < T && m < g.M) dst[(size_t)tap * MP + m] = acc[gi][R][q][v];
+                            }
+                        }
+                }
+            }
         }
     }
 }
@@ -346,8 +429,8 @@ __global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part
 }
 
 struct Plan {
-    int tilesX, tilesY, nct, npx, MP, TP, ng, ct;
-    size_t tiles, part_floats, lds;
+    int tilesX, tilesY, nct, npx, MP, TP, ng, ct, tpw;
+    size_t tiles, blocks, part_floats, lds;
 };
 
 bool plan_for(const cdl_geom *g, Plan *p)
@@ -357,7 +440,10 @@ bool plan_for(const cdl_geom *g, Plan *p)
     if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     const int MT = (g->M + 31) / 32;
-    const int CT = MT == 1 ? 1 : 2;                       // (one tile per wave for M = 64 doubles the LDS gathers: slower)   // one channel tile per wave when the waves divide evenly
+    // one channel tile per wave whenever the waves divide evenly: half the accumulators (room for the fat
+    // prefetch and the tree reduction without spills) for twice the -- now cheap -- LDS gathers; measured at cfg3 / cfg4:
+    // 88.6 / 56.4 us against 94 / 70 with two tiles per wave
+    const int CT = (MT == 1 || MT == 2 || MT == 4 || MT == 8) ? 1 : 2;
     p->ct = CT;
     p->nct = (MT + CT - 1) / CT;
     if (p->nct > 8) return false;                          // M <= 512
@@ -368,6 +454,8 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->tilesX = (Wz + GLX - 1) / GLX;
     p->tilesY = (Hz + GLY - 1) / GLY;
     p->tiles = (size_t)g->N * Dz * p->tilesX * p->tilesY;
+    p->tpw = 1;
+    p->blocks = p->tiles;                                  // upper bound (the launch groups tiles by the CU count)
     p->part_floats = p->tiles * g->C * g->Pd * p->TP * p->MP;
     const size_t XH = (size_t)(GLY - 1) * g->sh + g->Ph, XW = (size_t)(GLX - 1) * g->sw + g->Pw;
     p->ng = 1;                                             // groups held at once: registers (NG*RT*CT*16 <= 192) and LDS permitting
@@ -389,7 +477,9 @@ int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gat
               hipStream_t st)
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
-    k_wgm<PH, PW, SW, NG, CT><<<(unsigned)p.tiles, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP);
+    k_wgm<PH, PW, SW, NG, CT><<<(unsigned)p.blocks, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP,
+                                                                     cdl_opts().fused_debug & (1024 | 2048 | 4096),
+                                                                     (int)p.tiles, p.tpw);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -413,7 +503,7 @@ int launch(const cdl_geom *g, const Plan &p, const float *F, const float *gate, 
     else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st);
     if (rc) return rc;
     const int G = g->C * g->Pd, T = g->Ph * g->Pw;
-    k_wgm_fold<<<G * T * ((g->M + 15) / 16), 256, 0, st>>>(ws, dw, alpha, (int)p.tiles, G, g->M, T, p.TP, p.MP);
+    k_wgm_fold<<<G * T * ((g->M + 15) / 16), 256, 0, st>>>(ws, dw, alpha, (int)p.blocks, G, g->M, T, p.TP, p.MP);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -432,6 +522,9 @@ int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const f
 {
     Plan p;
     if (!plan_for(g, &p) || !ws || ws_floats < p.part_floats) return CDL_EUNSUPPORTED;
+    const size_t cus = (size_t)cdl_cu_count();              // one workgroup per CU at a time (registers): tiles per
+    p.tpw = (int)((p.tiles + cus - 1) / cus);               // workgroup = the number of rounds a tile-per-workgroup grid takes
+    p.blocks = (p.tiles + p.tpw - 1) / p.tpw;
 #define CDL_M(P_, S_) \
     if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream))
     CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
