@@ -46,6 +46,7 @@ SIGNATURES = {
     "cdl_synthesis": [_G, _P, _P, _P, _F, _P, _P, _P, _P],
     "cdl_synthesis_ws": [_G, _P, _P, _P, _F, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_wgrad": [_G, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
+    "cdl_wgrad_pair": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, ctypes.c_size_t, _P],
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_tau_grad_gate": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_analysis_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],

@@ -144,6 +144,8 @@ size_t cdl_mfma_analysis_ws_floats(const cdl_geom *g);
 // matrix-core filter gradients (cdl_wgrad_mfma.hip), same convention
 int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
                    float *ws, size_t ws_floats, void *stream);
+int cdl_mfma_wgrad_pair(const cdl_geom *g, const float *F0, const float *x0, float alpha0, float *dw0, const float *F1,
+                        const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats, void *stream);
 size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g);
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
                     float *dw, float *workspace, size_t workspace_floats, void *stream);

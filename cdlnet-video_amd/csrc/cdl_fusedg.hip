@@ -996,9 +996,7 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
         if (k >= 1) {
             rc = cdl_fusedg_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
             if (rc) return rc;
-            rc = cdl_wgrad(g, duk, nullptr, r[k - 1], -1.0f, dA[k], wgrad_ws, wgrad_ws_floats, stream);
-            if (rc) return rc;
-            rc = cdl_wgrad(g, z[k - 1], nullptr, q, 1.0f, dB[k], wgrad_ws, wgrad_ws_floats, stream);
+            rc = cdl_wgrad_pair(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wgrad_ws_floats, stream);
             thin = q;
         } else {
             rc = cdl_wgrad(g, duk, nullptr, yp, 1.0f, dA[0], wgrad_ws, wgrad_ws_floats, stream);

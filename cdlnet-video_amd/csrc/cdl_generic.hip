@@ -798,7 +798,7 @@ size_t cdl_wgrad_workspace_floats(const cdl_geom *g)
     // k_wgrad_l: one partial filter bank per 64 x 32 tile of code pixels (cdl_generic_tiled.hip)
     const size_t tiles = (size_t)g->N * (g->D / g->sd) * ((g->W / g->sw + 63) / 64) * ((g->H / g->sh + 31) / 32);
     const size_t by_tiles = tiles <= 4096 ? tiles * total : 0;                   // <= a few tens of MB
-    const size_t by_mfma = mfma_wgrad_enabled() ? cdl_mfma_wgrad_ws_floats(g) : 0;  // cdl_wgrad_mfma.hip
+    const size_t by_mfma = mfma_wgrad_enabled() ? 2 * cdl_mfma_wgrad_ws_floats(g) : 0;  // cdl_wgrad_mfma.hip (room for a paired launch)
     size_t a = by_rows > by_tiles ? by_rows : by_tiles;
     const size_t by_dense = mfma_dense_enabled() ? cdl_dense_wgrad_ws_floats(g) : 0;     // cdl_dense_mfma.hip
     if (by_dense > a) a = by_dense;
@@ -826,6 +826,22 @@ int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate, const float 
     k_wgrad<<<grid, 256, 0, S(stream)>>>(*g, z, gate, x, alpha, dw);
     CDL_LAUNCH_CHECK();
     return 0;
+}
+
+/* dw0 = alpha0 * z0 (x) x0 and dw1 = alpha1 * z1 (x) x1 (both ungated, same geometry): one paired matrix-core launch
+ * where the shape has one (cdl_wgrad_mfma.hip), two cdl_wgrad calls otherwise.  Same workspace as cdl_wgrad. */
+int cdl_wgrad_pair(const cdl_geom *g, const float *z0, const float *x0, float alpha0, float *dw0, const float *z1,
+                   const float *x1, float alpha1, float *dw1, float *workspace, size_t workspace_floats, void *stream)
+{
+    if (!cdl_geom_ok(g) || !z0 || !x0 || !dw0 || !z1 || !x1 || !dw1) return CDL_EINVAL;
+    if (g->Pw <= PWMAX && !cdl_opts().no_tiled && mfma_wgrad_enabled() &&
+        !(mfma_dense_enabled() && cdl_dense_wgrad_ws_floats(g) > 0)) {
+        const int rc = cdl_mfma_wgrad_pair(g, z0, x0, alpha0, dw0, z1, x1, alpha1, dw1, workspace, workspace_floats, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
+    const int rc = cdl_wgrad(g, z0, nullptr, x0, alpha0, dw0, workspace, workspace_floats, stream);
+    if (rc) return rc;
+    return cdl_wgrad(g, z1, nullptr, x1, alpha1, dw1, workspace, workspace_floats, stream);
 }
 
 static int tau_grad_impl(const cdl_geom *g, float *gup, const float *zout, const float *c, float *dt0, float *dt1,

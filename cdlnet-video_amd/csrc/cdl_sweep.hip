@@ -99,8 +99,7 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
             break;
         }
         CDL_TRY(cdl_synthesis_ws(g, gk, gate, wA[k], -1.0f, mask, nullptr, q, scratch, scratch_floats, stream));
-        CDL_TRY(cdl_wgrad(g, gk, gate, r[k - 1], -1.0f, dA[k], scratch, scratch_floats, stream));
-        CDL_TRY(cdl_wgrad(g, z[k - 1], nullptr, q, 1.0f, dB[k], scratch, scratch_floats, stream));
+        CDL_TRY(cdl_wgrad_pair(g, gk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], scratch, scratch_floats, stream));   // gk is gated in place above
         CDL_TRY(cdl_analysis_ws(g, q, wB[k], 1.0f, gk, gate, nullptr, other, scratch, scratch_floats, stream));
         float *t = gk;
         gk = other;

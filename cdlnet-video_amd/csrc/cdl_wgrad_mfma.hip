@@ -51,11 +51,17 @@ __device__ __forceinline__ unsigned int pack_bf16(float a, float b)
 // CT = 32-channel tiles per wave: 2 halves the LDS gathers per fat byte, 1 halves the accumulators (NG*RT*16 of them),
 // which is what lets two workgroups share a CU (<= 128 registers per lane) when NG*RT <= 5.
 template <int PH, int PW, int SW, int NG, int CT>
-__global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F,
-                                             const float *__restrict__ gate, const float *__restrict__ x,
-                                             float *__restrict__ part, int tilesX, int tilesY, int nct, int MP, int dbg,
-                                             int ntiles, int tpw)
+__global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F0,
+                                             const float *__restrict__ gate, const float *__restrict__ x0,
+                                             float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP, int dbg,
+                                             int ntiles, int tpw, const float *__restrict__ F1,
+                                             const float *__restrict__ x1)
 {
+    // blockIdx.y = 1: the second (fat, thin) operand pair of a paired launch (dA_k and dB_k of one iteration), its
+    // partial banks behind the first pair's
+    const float *__restrict__ F = blockIdx.y ? F1 : F0;
+    const float *__restrict__ x = blockIdx.y ? x1 : x0;
+    float *__restrict__ part = part0 + (size_t)blockIdx.y * gridDim.x * ((size_t)g.C * g.Pd * (((PH * PW + 31) / 32) * 32) * MP);
     constexpr int T = PH * PW, RT = (T + 31) / 32, TP = RT * 32;
     constexpr int XH = (GLY - 1) * SW + PH, XW = (GLX - 1) * SW + PW;
     constexpr int XE = ((XH * XW + 7) / 8) * 8;            // elements per bf16 plane (16-byte multiple)
@@ -403,9 +409,13 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
 // sums per workgroup, combined in a fixed order.  The 16 outputs of a workgroup are 16 consecutive channels of one
 // (grp, tap): every partial read is one 64-byte segment (with consecutive taps per workgroup the same reads were
 // 256 bytes apart and fetched 4x the bytes).
-__global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part, float *__restrict__ dw, float alpha,
-                                                  int nparts, int G, int M, int T, int TP, int MP)
+__global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part0, float *__restrict__ dw0, float alpha0,
+                                                  int nparts, int G, int M, int T, int TP, int MP,
+                                                  float *__restrict__ dw1, float alpha1)
 {
+    const float *__restrict__ part = part0 + (size_t)blockIdx.y * nparts * ((size_t)G * TP * MP);
+    float *__restrict__ dw = blockIdx.y ? dw1 : dw0;
+    const float alpha = blockIdx.y ? alpha1 : alpha0;
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, ps = threadIdx.x >> 4;
     const int mblocks = (M + 15) / 16;
@@ -474,36 +484,38 @@ bool plan_for(const cdl_geom *g, Plan *p)
 
 template <int PH, int PW, int SW, int NG, int CT>
 int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
-              hipStream_t st)
+              hipStream_t st, const float *F1, const float *x1)
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
-    k_wgm<PH, PW, SW, NG, CT><<<(unsigned)p.blocks, GNT, p.lds, st>>>(*g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP,
-                                                                     cdl_opts().fused_debug & (1024 | 2048 | 4096),
-                                                                     (int)p.tiles, p.tpw);
+    k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1), GNT, p.lds, st>>>(
+        *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP, cdl_opts().fused_debug & (1024 | 2048 | 4096), (int)p.tiles,
+        p.tpw, F1, x1);
     CDL_LAUNCH_CHECK();
     return 0;
 }
 
 template <int PH, int PW, int SW, int NG>
 int launch_ng(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
-              hipStream_t st)
+              hipStream_t st, const float *F1, const float *x1)
 {
-    return p.ct == 1 ? launch_ct<PH, PW, SW, NG, 1>(g, p, F, gate, x, ws, st)
-                     : launch_ct<PH, PW, SW, NG, 2>(g, p, F, gate, x, ws, st);
+    return p.ct == 1 ? launch_ct<PH, PW, SW, NG, 1>(g, p, F, gate, x, ws, st, F1, x1)
+                     : launch_ct<PH, PW, SW, NG, 2>(g, p, F, gate, x, ws, st, F1, x1);
 }
 
 template <int PH, int PW, int SW>
 int launch(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float alpha,
-           float *dw, float *ws, hipStream_t st)
+           float *dw, float *ws, hipStream_t st, const float *F1 = nullptr, const float *x1 = nullptr,
+           float alpha1 = 0.0f, float *dw1 = nullptr)
 {
     constexpr int RT = (PH * PW + 31) / 32;
     int rc;
-    if (RT == 1 && p.ng == 5) rc = launch_ng<PH, PW, SW, (RT == 1 ? 5 : 1)>(g, p, F, gate, x, ws, st);
-    else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st);
-    else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st);
+    if (RT == 1 && p.ng == 5) rc = launch_ng<PH, PW, SW, (RT == 1 ? 5 : 1)>(g, p, F, gate, x, ws, st, F1, x1);
+    else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st, F1, x1);
+    else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st, F1, x1);
     if (rc) return rc;
     const int G = g->C * g->Pd, T = g->Ph * g->Pw;
-    k_wgm_fold<<<G * T * ((g->M + 15) / 16), 256, 0, st>>>(ws, dw, alpha, (int)p.blocks, G, g->M, T, p.TP, p.MP);
+    k_wgm_fold<<<dim3(G * T * ((g->M + 15) / 16), F1 ? 2 : 1), 256, 0, st>>>(ws, dw, alpha, (int)p.blocks, G, g->M, T,
+                                                                             p.TP, p.MP, dw1, alpha1);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -517,18 +529,34 @@ size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g)
 }
 
 // CDL_EUNSUPPORTED: the caller falls back to the VALU kernels
-int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
-                   float *ws, size_t ws_floats, void *stream)
+static int wgrad_entry(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                       const float *F1, const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats,
+                       void *stream)
 {
     Plan p;
-    if (!plan_for(g, &p) || !ws || ws_floats < p.part_floats) return CDL_EUNSUPPORTED;
+    if (!plan_for(g, &p) || !ws) return CDL_EUNSUPPORTED;
+    const size_t jobs = F1 ? 2 : 1;
     const size_t cus = (size_t)cdl_cu_count();              // one workgroup per CU at a time (registers): tiles per
-    p.tpw = (int)((p.tiles + cus - 1) / cus);               // workgroup = the number of rounds a tile-per-workgroup grid takes
+    p.tpw = (int)((jobs * p.tiles + cus - 1) / cus);        // workgroup = the number of rounds a tile-per-workgroup grid takes
     p.blocks = (p.tiles + p.tpw - 1) / p.tpw;
+    if (ws_floats < jobs * p.blocks * ((size_t)g->C * g->Pd * p.TP * p.MP)) return CDL_EUNSUPPORTED;
 #define CDL_M(P_, S_) \
-    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream))
+    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream), F1, x1, alpha1, dw1)
     CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
     CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
 #undef CDL_M
     return CDL_EUNSUPPORTED;
+}
+
+int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
+                   float *ws, size_t ws_floats, void *stream)
+{
+    return wgrad_entry(g, F, gate, x, alpha, dw, nullptr, nullptr, 0.0f, nullptr, ws, ws_floats, stream);
+}
+
+// Two ungated filter gradients of the same geometry (dA_k = a0 F0 (x) x0, dB_k = a1 F1 (x) x1) in ONE launch + ONE fold
+int cdl_mfma_wgrad_pair(const cdl_geom *g, const float *F0, const float *x0, float alpha0, float *dw0, const float *F1,
+                        const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats, void *stream)
+{
+    return wgrad_entry(g, F0, nullptr, x0, alpha0, dw0, F1, x1, alpha1, dw1, ws, ws_floats, stream);
 }

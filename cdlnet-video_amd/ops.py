@@ -277,6 +277,24 @@ def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):
     return dw
 
 
+def wgrad_pair(g: Geometry, z0, x0, alpha0, z1, x1, alpha1):
+    """(alpha0 * z0 (x) x0, alpha1 * z1 (x) x1): the two ungated filter gradients of one reverse iteration, one
+    launch where the matrix-core kernel covers the shape (cdl_wgrad_pair)."""
+    z0, x0, z1, x1 = _dev(z0, "z0"), _dev(x0, "x0"), _dev(z1, "z1"), _dev(x1, "x1")
+    dw0 = torch.empty(g.filter_shape(), device=z0.device, dtype=torch.float32)
+    dw1 = torch.empty_like(dw0)
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_wgrad_workspace_floats(ctypes.byref(gs)))
+    key = (z0.device, n)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(max(n, 1), device=z0.device, dtype=torch.float32)
+    rc = _lib.lib().cdl_wgrad_pair(ctypes.byref(gs), _ptr(z0), _ptr(x0), float(alpha0), _ptr(dw0), _ptr(z1), _ptr(x1),
+                                   float(alpha1), _ptr(dw1), _ptr(ws), n, _stream())
+    _lib.check(rc, "cdl_wgrad_pair")
+    return dw0, dw1
+
+
 def tau_grad(g: Geometry, gup, zout, c, dt_k):
     """Writes the (2,M) slice `dt_k` of the threshold gradient for one iteration."""
     gup, zout, c = _dev(gup, "g"), _dev(zout, "zout"), _opt(c, "c")

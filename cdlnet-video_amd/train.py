@@ -83,7 +83,8 @@ def mcsure_loss(net, obsrv, xhat, sigma, mask=1, h=1e-3, generator=None, b=None)
         mean((obsrv - xhat)^2) + 2 * mean((sigma/255)^2 * b * (net(obsrv + h b) - xhat)) / h
     Gradients flow through both forward passes (both run in the HIP kernels)."""
     if b is None:
-        b = torch.randn(obsrv.shape, device=obsrv.device, dtype=obsrv.dtype, generator=generator)
+        dev = generator.device if generator is not None else obsrv.device
+        b = torch.randn(obsrv.shape, device=dev, dtype=obsrv.dtype, generator=generator).to(obsrv.device)
     xhat_b, _ = net(obsrv.clone() + h * b, sigma, mask=mask)
     s2 = (sigma / 255.0) ** 2
     div = 2.0 * torch.mean(s2 * b * (xhat_b - xhat)) / h
@@ -150,7 +151,7 @@ def save_args(args, ckpt=True):
 
 def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), save_dir=None, start_epoch=1,
         clip_grad=1, noise_std=25, demosaic=False, verbose=True, val_freq=1, save_freq=1, epoch_fun=None,
-        mcsure=False, backtrack_thresh=1, grad_sync=None, log=print, group=None):
+        mcsure=False, backtrack_thresh=1, grad_sync=None, log=print, group=None, generator=None):
     """The reference's training driver (train.py:35-158), same arguments and files:
 
     * phases train / val (every `val_freq` epochs) / test (only at `epoch == epochs`, as written there);
@@ -161,7 +162,9 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
       rewind `epoch` to the checkpointed one and log it in `backtrack.txt`;
     * scheduler step per epoch; `net.ckpt` (+ `epoch_fun(epoch)`) every `save_freq` epochs; `0.ckpt` at start.
 
-    `loaders` maps phase -> iterable of clean batches.  `grad_sync` (new) is run after backward for data
+    `loaders` maps phase -> iterable of clean batches.  `generator` (new): the torch.Generator every noise draw uses;
+    a CPU generator (torch.default_generator after torch.manual_seed) reproduces the random stream of the reference's
+    CPU run on a GPU run (tests/test_gpu_trainer.py replays a reference-generated trajectory that way).  `grad_sync` (new) is run after backward for data
     parallel training (parallel.GradientBucket.sync).  Under data parallelism (an initialised process
     group; `group` selects it) every rank sees a different shard, so the decisions that change the
     training state are taken on REDUCED values: the phase PSNR is the mean over all ranks' batches and the
@@ -213,11 +216,11 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
                 batch = batch.to(device)
                 if phase == "train":
                     loss_t, _ = train_step(net, opt, batch, phase_nstd, clip_grad=clip_grad, demosaic=demosaic,
-                                           grad_sync=grad_sync, mcsure=mcsure)
+                                           grad_sync=grad_sync, mcsure=mcsure, generator=generator)
                 else:
                     with torch.no_grad():
                         mask = gen_bayer_mask(batch) if demosaic else 1
-                        noisy, sigma = awgn(batch, phase_nstd)
+                        noisy, sigma = awgn(batch, phase_nstd, generator)
                         xhat, _ = net(mask * noisy, sigma, mask=mask)
                         loss_t = torch.mean((batch - xhat) ** 2)
                 loss = float(loss_t)

@@ -24,13 +24,16 @@ def gen_bayer_mask3d(x):
 
 
 def _awgn(x, noise_std, generator=None):
+    # The draws happen on the generator's device and in the reference's order (rand for sigma, then randn): with a
+    # CPU generator (e.g. torch.default_generator) a GPU run sees the very noise the reference's CPU path draws.
+    dev = generator.device if generator is not None else x.device
     if isinstance(noise_std, (list, tuple)):
         shape = (len(x),) + (1,) * (x.dim() - 1)
         sigma = noise_std[0] + (noise_std[1] - noise_std[0]) * torch.rand(
-            shape, device=x.device, generator=generator)
+            shape, device=dev, generator=generator).to(x.device)
     else:
         sigma = noise_std
-    noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=generator)
+    noise = torch.randn(x.shape, device=dev, dtype=x.dtype, generator=generator).to(x.device)
     return x + noise * (sigma / 255), sigma
 
 

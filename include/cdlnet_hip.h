@@ -123,6 +123,12 @@ size_t cdl_synthesis_workspace_floats(const cdl_geom *g);
  * dB_k: (z=z_k, x=q_k, alpha=+1).  Deterministic (no atomics).  Pw <= 16. dw is overwritten. */
 int cdl_wgrad(const cdl_geom *g, const float *z, const float *gate /*nullable*/, const float *x,
               float alpha, float *dw, float *workspace /*nullable*/, size_t workspace_floats, void *stream);
+/* Two UNGATED filter gradients of one geometry -- the dA_k / dB_k pair of an iteration of the reverse sweep
+ * (train.py:98 through net.py:87 / 204-207) -- as one launch where the matrix-core kernel covers the shape; otherwise two
+ * cdl_wgrad calls.  Same results as two calls, same workspace (cdl_wgrad_workspace_floats). */
+int cdl_wgrad_pair(const cdl_geom *g, const float *z0, const float *x0, float alpha0, float *dw0, const float *z1,
+                   const float *x1, float alpha1, float *dw1, float *workspace, size_t workspace_floats,
+                   void *stream);
 /* Scratch (floats) that lets cdl_wgrad split the pixel range over more workgroups (two-stage,
  * fixed-order reduction).  Without a workspace a slower single-stage kernel is used. */
 size_t cdl_wgrad_workspace_floats(const cdl_geom *g);

@@ -122,9 +122,14 @@ def test_filter_and_threshold_grads(N, C, M, sp, P, s, path, hip_env):
     tag = f"wgrad[{path}] N{N}C{C}M{M}{sp}P{P}s{s}"
     wtol = 2e-5 if path == "mfma" else 1e-5           # split-bf16 x3 operands (as the fused kernels) vs fp32 FMAs
     check(tag + " gated", o.wgrad(geom, u.cuda(), x.cuda(), 1.0, gate=z.cuda()), wv.grad, wtol)
+    g_ana = wv.grad.clone()
     wv.grad = None
     (O.synthesis(z, wv, s, pad) * x).sum().backward()
     check(tag + " synth", o.wgrad(geom, z.cuda(), x.cuda(), -2.0), -2.0 * wv.grad, wtol)
+    # the dA_k / dB_k pair of a reverse iteration as one launch (cdl_wgrad_pair; gradient gated upstream)
+    d0, d1 = o.wgrad_pair(geom, (u * (z != 0)).cuda(), x.cuda(), 1.0, z.cuda(), x.cuda(), -2.0)
+    check(tag + " pair[0]", d0, g_ana, wtol)
+    check(tag + " pair[1]", d1, -2.0 * wv.grad, wtol)
     # threshold gradient
     c = torch.rand(N)
     dt = torch.zeros(2, M, device="cuda")
