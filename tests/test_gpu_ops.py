@@ -33,6 +33,9 @@ SHAPES = [
     # the argscsr.json filter bank: 9 x 9, stride 2, 169 code channels -- weight fragments stream through LDS in
     # chunks of k-steps in the matrix-core synthesis, channel groups in the analysis
     (12, 1, 169, (68, 132), (9, 9), 2),
+    # the shipped s2030 filter bank with enough tiles (80) for the matrix-core filter gradient: 6 channel tiles = 3 wave
+    # groups x 2 pixel parts, two waves idle in the tree reduction
+    (20, 1, 169, (68, 132), (7, 7), 2),
     # many channels on both sides, unit stride: the dense matrix-core tier (cdl_dense_mfma.hip; the ResidualBlock's
     # Conv3d(M, M) and its data gradient), ragged channel chunks (24 = 16 + 8), M over two workgroup groups, 2-D
     (2, 16, 32, (3, 17, 33), (3, 3, 3), 1),
