@@ -777,18 +777,45 @@ __global__ __launch_bounds__(256) void k_assemble_v4(const float *__restrict__ p
                                                      float alpha, float *__restrict__ out, int N, int H, int W,
                                                      int tilesX, int tilesY)
 {
+    // 4 consecutive pixels x 2 rows per thread.  The terms of a pixel are added in patch_sum's order (row above, own
+    // row, row below; left neighbour, own tile, right neighbour), but the row candidates are wave-uniform branches and
+    // the 8 loads of a patch row (4 own + up to 4 from the horizontal neighbour) are issued side by side instead of as
+    // per-pixel dependent chains.  X is a multiple of 4 and TW of 64: the 4 pixels share their tile.
     const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, n = blockIdx.z;
     if (X >= W) return;
+    const int txc = X / TW, lx = X - txc * TW;
+    int hx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        hx[e] = (lx + e < HALO && txc > 0) ? -1 : ((lx + e >= TW - HALO && txc + 1 < tilesX) ? 1 : 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int Y = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2 + j;
         if (Y >= H) break;
+        const int tyc = Y / TH, ly = Y - tyc * TH;
+        const int vy = (ly < HALO && tyc > 0) ? -1 : ((ly >= TH - HALO && tyc + 1 < tilesY) ? 1 : 0);        // uniform
+        const float *own = patches + (((size_t)n * tilesY + tyc) * tilesX + txc) * SLAB + (ly + HALO) * RTW + lx + HALO;
+        const ptrdiff_t dy = (ptrdiff_t)vy * ((ptrdiff_t)tilesX * SLAB - TH * RTW);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto row = [&](ptrdiff_t off) {
+            float a[4], b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = own[off + e];
+                b[e] = hx[e] != 0 ? own[off + e + (ptrdiff_t)hx[e] * (SLAB - TW)] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (hx[e] < 0) acc[e] += b[e];
+                acc[e] += a[e];
+                if (hx[e] > 0) acc[e] += b[e];
+            }
+        };
+        if (vy < 0) row(dy);
+        row(0);
+        if (vy > 0) row(dy);
         const size_t i = ((size_t)n * H + Y) * W + X;
-        float4 v;
-        v.x = alpha * patch_sum(patches, n, Y, X, tilesX, tilesY);
-        v.y = alpha * patch_sum(patches, n, Y, X + 1, tilesX, tilesY);
-        v.z = alpha * patch_sum(patches, n, Y, X + 2, tilesX, tilesY);
-        v.w = alpha * patch_sum(patches, n, Y, X + 3, tilesX, tilesY);
+        float4 v = make_float4(alpha * acc[0], alpha * acc[1], alpha * acc[2], alpha * acc[3]);
         if (mask) {
             const float4 m = *reinterpret_cast<const float4 *>(mask + i);
             v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
