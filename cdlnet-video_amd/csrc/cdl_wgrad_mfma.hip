@@ -27,13 +27,16 @@ constexpr int LDS_MAX = 128 * 1024;
 // Unit stride: the thin tile is kept as bf16 PAIRS, twice -- plane E holds (x[2c], x[2c+1]), plane O holds
 // (x[2c+1], x[2c+2]) -- so that the 8 consecutive pixels of an im2col row are 4 whole dwords whatever the parity of the
 // tap column (a 16-byte read at 2-byte alignment costs ~8x an aligned one: the first version spent 60-70 % of the
-// launch in the LDS pipe).  A plane is padded to 16 (mod 64) dwords: the E and O reads of one instruction then fall
-// into disjoint banks.
-constexpr int eo_row_dwords(int sw, int pw) { return ((GLX - 1) * sw + pw + 1) / 2; }
+// launch in the LDS pipe).  The reads are ds_read2_b32: 32 banks, the 32 lanes (= taps) of a half-wave form a group.
+// Tap (ki, kj) reads dword  plane(kj & 1) + ki * RD + (kj >> 1)  (+ a wave-uniform offset), so with the row pitch
+// RD = P (mod 32) and the plane pitch PD = ceil(P / 2) (mod 32) the taps of a filter row fill P consecutive banks and
+// the rows follow each other: no two of the 32 taps of an instruction share a bank (P <= 5; two banks 2-way for P = 7).
+// (With the natural pitch 34 and the planes 16 apart, half of all LDS cycles of the k-loop were conflict cycles.)
+constexpr int pad_to(int d, int r) { return d + ((r - d % 32) + 32) % 32; }       // smallest d' >= d with d' = r (mod 32)
+constexpr int eo_row_dwords(int sw, int pw) { return pad_to(((GLX - 1) * sw + pw + 1) / 2, pw % 32); }
 constexpr int eo_plane_dwords(int sw, int ph, int pw)
 {
-    const int d = ((GLY - 1) * sw + ph) * eo_row_dwords(sw, pw);
-    return d + ((16 - d % 64) + 64) % 64;
+    return pad_to(((GLY - 1) * sw + ph) * eo_row_dwords(sw, pw), (pw + 1) / 2);
 }
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ unsigned int pack_bf16(float a, float b)
@@ -181,6 +184,73 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         zd = b % Dz; n = b / Dz;
         fbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
         ybase = ty * GLY * SW - g.ph; xbase = tx * GLX * SW - g.pw;
+        // Fast path (rows are whole 32-byte segments: Wz % 8 == 0, 16-byte aligned bases): the fat operand of k-step
+        // ks+1 is loaded -- branch-free, at a clamped address -- while k-step ks is converted, gathered and multiplied.
+        // The first version issued the loads of a k-step and consumed them at once: every k-step exposed a global
+        // load latency (62 % of the wave cycles were waits, 20 % matrix-core utilisation).  One k-step ahead keeps
+        // 16 KB per CU in flight, which at ~1 us of loaded latency is the 4 TB/s the k-loop ran at; with NS = 4 slots
+        // (small accumulator sets) three k-steps are in flight, and the first ones of a tile are issued BEFORE its
+        // thin staging so they arrive under it.
+        // (ungated operands only -- the sweeps gate their gradients in place upstream; a gate would double the
+        //  prefetch registers and spill)
+        constexpr bool PREFETCH = NG * RT * CT * 16 <= 160;   // 32 prefetch registers next to the accumulators
+        const bool fast = PREFETCH && vec4 && (Wz & 7) == 0 && gate == nullptr;
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        constexpr int NS = NG * RT * CT * 16 <= 96 ? 4 : 2;  // ring slots
+        f32x4 fraw[NS][CT][2];                              // [slot][channel tile][half segment]
+
+        auto fat_issue = [&](int ks, f32x4 (&fr)[CT][2]) {
+            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
+            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
+#pragma unroll
+            for (int q = 0; q < CT; ++q) {
+                const int m = 32 * (CT * cg + q) + l32;
+                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
+                const size_t idx = ok ? fbase + (size_t)m * slab + (size_t)cy * Wz + cx0 : fbase;
+                fr[q][0] = *reinterpret_cast<const f32x4 *>(F + idx);
+                fr[q][1] = *reinterpret_cast<const f32x4 *>(F + idx + 4);
+            }
+        };
+        auto kstep = [&](int ks, const f32x4 (&fr)[CT][2]) {
+            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
+            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
+            bf16x8 bh[CT], bl[CT];
+#pragma unroll
+            for (int q = 0; q < CT; ++q) {
+                const int m = 32 * (CT * cg + q) + l32;
+                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = ok ? fr[q][i >> 2][i & 3] : 0.0f;
+                    const __bf16 hh = (__bf16)v;
+                    bh[q][i] = hh;
+                    bl[q][i] = (__bf16)(v - (float)hh);
+                }
+            }
+            // the im2col rows of tile t+1 are read from LDS while the products of tile t issue (a wait for every
+            // group's reads right before its MFMAs left the matrix pipe idle half of the k-loop)
+            bf16x8 ah[2], al[2];
+            gather(0, 0, zy, zx0, ah[0], al[0]);
+#pragma unroll
+            for (int t = 0; t < NG * RT; ++t) {
+                if (t + 1 < NG * RT) gather((t + 1) / RT, (t + 1) % RT, zy, zx0, ah[(t + 1) & 1], al[(t + 1) & 1]);
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    f32x16 &a = acc[t / RT][t % RT][q];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1], bh[q], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1], bl[q], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1], bh[q], a, 0, 0, 0);
+                }
+            }
+        };
+        const int k0 = pp * kpw, k1 = (pp + 1) * kpw;       // kpw is a power of two >= 16
+        const bool pipelined = PREFETCH && active && fast && !(dbg & 2048);
+        if constexpr (PREFETCH) {
+            if (pipelined) {
+#pragma unroll
+                for (int sl = 0; sl + 1 < NS; ++sl) fat_issue(k0 + sl, fraw[sl]);
+            }
+        }
         __syncthreads();                                   // previous tile / previous batch's reduction has read the buffer
         if constexpr (EO) {
             if (!(dbg & 1024)) {                           // (CDL_FUSED_DEBUG bits 1024 / 2048 / 4096: timing ablations)
@@ -213,70 +283,15 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             }
         }
         __syncthreads();
-        // Fast path (rows are whole 32-byte segments: Wz % 8 == 0, 16-byte aligned bases): the fat operand of k-step
-        // ks+1 is loaded -- branch-free, at a clamped address -- while k-step ks is converted, gathered and multiplied.
-        // The first version issued the loads of a k-step and consumed them at once: every k-step exposed a global
-        // load latency (62 % of the wave cycles were waits, 20 % matrix-core utilisation).
-        // (ungated operands only -- the sweeps gate their gradients in place upstream; a gate would double the
-        //  prefetch registers and spill)
-        constexpr bool PREFETCH = NG * RT * CT * 16 <= 160;   // 32 prefetch registers next to the accumulators
-        const bool fast = PREFETCH && vec4 && (Wz & 7) == 0 && gate == nullptr;
-        typedef __attribute__((ext_vector_type(4))) float f32x4;
-        f32x4 fraw[2][CT][2];                               // [ping-pong][channel tile][half segment]
-        auto fat_issue = [&](int ks, f32x4 (&fr)[CT][2]) {
-            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
-            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
-#pragma unroll
-            for (int q = 0; q < CT; ++q) {
-                const int m = 32 * (CT * cg + q) + l32;
-                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
-                const size_t idx = ok ? fbase + (size_t)m * slab + (size_t)cy * Wz + cx0 : fbase;
-                fr[q][0] = *reinterpret_cast<const f32x4 *>(F + idx);
-                fr[q][1] = *reinterpret_cast<const f32x4 *>(F + idx + 4);
-            }
-        };
-        auto kstep = [&](int ks, const f32x4 (&fr)[CT][2]) {
-            const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;
-            const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
-            bf16x8 bh[CT], bl[CT];
-#pragma unroll
-            for (int q = 0; q < CT; ++q) {
-                const int m = 32 * (CT * cg + q) + l32;
-                const bool ok = m < g.M && cy < Hz && cx0 < Wz;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float v = ok ? fr[q][i >> 2][i & 3] : 0.0f;
-                    const __bf16 hh = (__bf16)v;
-                    bh[q][i] = hh;
-                    bl[q][i] = (__bf16)(v - (float)hh);
-                }
-            }
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-                for (int R = 0; R < RT; ++R) {
-                    bf16x8 ah, al;
-                    gather(gi, R, zy, zx0, ah, al);
-#pragma unroll
-                    for (int q = 0; q < CT; ++q) {
-                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[gi][R][q], 0, 0, 0);
-                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[gi][R][q], 0, 0, 0);
-                        acc[gi][R][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[gi][R][q], 0, 0, 0);
-                    }
-                }
-        };
-        bool pipelined = false;
         if constexpr (PREFETCH) {
-            if (active && fast && !(dbg & 2048)) {
-                pipelined = true;
-                const int k0 = pp * kpw, k1 = (pp + 1) * kpw;   // kpw is even (a power of two >= 16)
-                fat_issue(k0, fraw[0]);
+            if (pipelined) {
 #pragma unroll 1
-                for (int ks = k0; ks < k1; ks += 2) {
-                    fat_issue(ks + 1, fraw[1]);
-                    kstep(ks, fraw[0]);
-                    if (ks + 2 < k1) fat_issue(ks + 2, fraw[0]);
-                    kstep(ks + 1, fraw[1]);
+                for (int ks = k0; ks < k1; ks += NS) {
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) {       // (past the end: the last k-step again, never consumed)
+                        fat_issue(min(ks + sl + NS - 1, k1 - 1), fraw[(sl + NS - 1) % NS]);
+                        kstep(ks + sl, fraw[sl]);
+                    }
                 }
             }
         }
