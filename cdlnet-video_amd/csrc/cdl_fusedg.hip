@@ -28,6 +28,7 @@
 // fp32-grade accuracy on the bf16 matrix cores by the hi/lo split of cdl_fused2d.hip (3 MFMAs per product).
 // Arithmetic intensity: 93 (cfg3) / 132 (cfg4) MFMA instructions per 32 voxels against 12-16 KB of fat traffic: this
 // kernel needs ~50 % matrix-core utilisation to be HBM-bound (the 2-D flagship kernel: 16 %).
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -69,6 +70,7 @@ struct GParams {
     float sgn;
     int do_synth;
     int N, C, M, D, H, W, Pd, tilesX, tilesY, KS, rev;
+    unsigned long long *tl;  // profiling hook (cdl_fusedg_set_timeline): s_memtime stamps of workgroup 0, [wave][256]
     int dbg;                 // timing experiments only (CDL_FUSED_DEBUG; results are wrong): 1 no thin staging after the
                              // first tile, 2 no analysis GEMM, 4 no synthesis / col2im, 8 no fat loads, 16 no fat stores,
                              // 32 no patch combine
@@ -231,6 +233,10 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
     const int c = lane & 31, h = lane >> 5;
     const size_t HW = (size_t)p.H * p.W, DHW = (size_t)p.D * HW;
     const int K = G * P * P;
+    int tli = 0;
+    const bool tl_on = p.tl != nullptr && blockIdx.x == 0;      // uniform
+#define CDL_TL() do { if (tl_on) { if (lane == 0 && tli < 256) p.tl[wid * 256 + tli] = __builtin_readcyclecounter(); ++tli; } } while (0)
+    CDL_TL();
     const int FA = MT * KS, FB = G * RT * KQ;
     const int numTiles = p.N * p.D * p.tilesY * p.tilesX;
 
@@ -280,24 +286,35 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
     // thin planes of a tile: plane g = (c, kd) is depth zd - Pd/2 + kd of channel c.  Loaded into registers one tile
     // ahead (after the row loop of the previous tile, so the loads fly during its patch combine), converted and
     // stored to LDS at the top of the tile.
+    // The loads are branch-free (clamped addresses); whether an element is inside the image (per thread, stg_ok) and
+    // whether a plane exists (uniform, stg_planes) is applied when the values are converted, one tile later.
     float stg[G][NSTG];
+    bool stg_ok[NSTG];
+    unsigned stg_planes = 0;
     auto stage_load = [&](int t) {
+        const bool skip = t >= numTiles || ((p.dbg & 1) && t != (int)blockIdx.x);
         int bid = p.rev ? numTiles - 1 - t : t;
+        bid = skip ? 0 : bid;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
         const int tyi = bid % p.tilesY; bid /= p.tilesY;
         const int zd = bid % p.D, n = bid / p.D;
-        const bool skip = t >= numTiles || ((p.dbg & 1) && t != (int)blockIdx.x);
+        int off[NSTG];
+#pragma unroll
+        for (int k = 0; k < NSTG; ++k) {
+            const int yy = tyi * TH - HALO + stg_row[k], xx = txi * TW - HALO + stg_col[k];
+            stg_ok[k] = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            off[k] = min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1);
+        }
+        stg_planes = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int kd = g % p.Pd, cc = g / p.Pd;
             const int d = zd - p.Pd / 2 + kd;
-            const bool dok = !skip && d >= 0 && d < p.D;
+            const bool dok = !skip && d >= 0 && d < p.D;     // uniform
+            stg_planes |= (dok ? 1u : 0u) << g;
             const float *plane = p.r + (((size_t)n * p.C + cc) * p.D + (dok ? d : 0)) * HW;
 #pragma unroll
-            for (int k = 0; k < NSTG; ++k) {
-                const int yy = tyi * TH - HALO + stg_row[k], xx = txi * TW - HALO + stg_col[k];
-                stg[g][k] = (dok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? plane[yy * p.W + xx] : 0.0f;
-            }
+            for (int k = 0; k < NSTG; ++k) stg[g][k] = plane[off[k]];
         }
     };
     auto stage_store = [&]() {
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
 #pragma unroll
             for (int k = 0; k < NSTG; ++k) {
                 const int i = tid + k * NT;
-                const float v = stg[g][k];
+                const float v = (stg_ok[k] && ((stg_planes >> g) & 1u)) ? stg[g][k] : 0.0f;
                 const __bf16 hh = (__bf16)v;
                 if (i < XH * XW) {
                     xh[g * PS + i] = hh;
@@ -324,11 +341,16 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
         const int tyi = bid % p.tilesY; bid /= p.tilesY;
         const int zd = bid % p.D, n = bid / p.D;
         const int tx0 = txi * TW, ty0 = tyi * TH;
+        CDL_TL();
         __syncthreads();                                     // previous tile's readers are done (and the tables are in)
+        CDL_TL();
         stage_store();                                       // thin planes of this tile (loaded into registers earlier)
         if (MODE != MODE_BWD && tid < 64) tau_s[tid] = tid < M ? p.tau[(size_t)n * M + tid] : 0.0f;
-        for (int i = lane; i < G * WPE; i += 64) wp[i] = 0.0f;          // this wave's private patch
+        // (the wave's private patch needs no zeroing: the row loop stores rows 0 .. RB-1, the ring flush rows RB .. WPH-1,
+        //  every column)
+        CDL_TL();
         __syncthreads();
+        CDL_TL();
         // thresholds are >= 0 whenever project() runs (net.py:70); a negative one (3-D trainer, never projected)
         // sends the whole tile through the general shrinkage -- wave-uniform, so the common case pays 3 instructions
         // per element instead of 10
@@ -430,6 +452,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             }
 
             __builtin_amdgcn_sched_barrier(0);
+            CDL_TL();
             // -- epilogue: register v of tile R is channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c
             auto epilogue = [&](auto general_shrink) {
             int so = s_row;
@@ -489,6 +512,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             if (p.dbg & 4) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
             __builtin_amdgcn_sched_barrier(0);
+            CDL_TL();
             // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand; split once,
             //    reused by every group
             bf16x8 zh[2 * MT], zl[2 * MT];
@@ -549,6 +573,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 for (int i = 0; i + 1 < P; ++i) ring[g][i] = ring[g][i + 1];
                 ring[g][P - 1] = 0.0f;
             }
+            CDL_TL();
         }
         // ---- the P-1 output rows below the wave's last image row are still in the ring
         if (MODE != MODE_BWD || p.do_synth) {
@@ -568,8 +593,11 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 tacc_s[wid * 64 + 32 * R + 8 * (v >> 2) + 4 * h + (v & 3)] = tot;
             }
         }
+        CDL_TL();
         stage_load(t + gridDim.x);                           // next tile's thin loads fly during the combine below
+        CDL_TL();
         __syncthreads();                                     // every wave's patch (and tacc) is complete
+        CDL_TL();
         if (MODE == MODE_BWD && tid < 64) {
             float sacc = 0.0f;
 #pragma unroll
@@ -580,23 +608,60 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             // tile patch = fixed-order sum (wave row, then wave column) of the wave patches covering each element;
             // CROWS patch rows per pass, one thread per element
             float *patch = p.patches + (size_t)tile * G * (PY * PX);
-            if (cmb_row < CROWS) {
-                const int wx_lo = cmb_col >= 32 ? 1 : 0, wx_hi = cmb_col < WPW ? 0 : 1;      // waves (x) covering this column
-                for (int rr = cmb_row; rr < G * PY; rr += CROWS) {
-                    const int g = rr / PY, Y = rr - g * PY;
-                    float sum = 0.0f;
+            // (the empty asm keeps everything derived from the thread's patch position INSIDE the tile loop: hoisted, the
+            //  offsets live across the row loop and spill)
+            int ccol = cmb_col, crow = cmb_row;
+            asm volatile("" : "+v"(ccol), "+v"(crow));
+            if (crow < CROWS) {
+                // an element is covered by at most NCY = ceil(WPH / RB) wave rows x 2 wave columns.  A thread owns one
+                // patch column and the rows Y = cmb_row + CROWS j; which wave rows cover Y does not depend on the group,
+                // so the candidate offsets are worked out once per j and the G groups follow at constant offsets, their
+                // reads issued side by side; terms are added in the same order as before (wave row, then wave column;
+                // absent candidates skipped).
+                const int wx_lo = ccol >= 32 ? 1 : 0, wx_hi = ccol < WPW ? 0 : 1;      // waves (x) covering this column
+                const bool two_x = wx_hi < wx_lo;
+                constexpr int NCY = (WPH + RB - 1) / RB;
+                constexpr int NJ = (PY + CROWS - 1) / CROWS;
+                const float *col_hi = wp_all + (size_t)wx_hi * G * WPE + (ccol - wx_hi * 32);
+                const float *col_lo = wp_all + (size_t)wx_lo * G * WPE + (ccol - wx_lo * 32);
 #pragma unroll
-                    for (int wy = 0; wy < WY; ++wy) {
-                        const int ry = Y - wy * RB;
-                        if (ry < 0 || ry >= WPH) continue;
-                        for (int wx = wx_hi; wx <= wx_lo; ++wx)
-                            sum += wp_all[((size_t)(wy * WX + wx) * G + g) * WPE + ry * WPW + (cmb_col - wx * 32)];
+                for (int j = 0; j < NJ; ++j) {
+                    const int Y = crow + CROWS * j;
+                    const bool rowok = Y < PY;
+                    const int Yc = min(Y, PY - 1);
+                    const int wy1 = min(Yc / RB, WY - 1);                             // the last covering wave row
+                    int off[NCY];
+                    bool oky[NCY];
+#pragma unroll
+                    for (int a = 0; a < NCY; ++a) {                                   // ascending wave rows
+                        const int wy = wy1 - (NCY - 1) + a, ry = Yc - wy * RB;
+                        oky[a] = wy >= 0 && ry < WPH;
+                        off[a] = max(wy, 0) * (WX * G * WPE) + min(ry, WPH - 1) * WPW;
                     }
-                    patch[rr * PX + cmb_col] = sum;
+                    float v[G][2 * NCY];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int a = 0; a < NCY; ++a) {
+                            v[g][2 * a] = col_hi[off[a] + g * WPE];
+                            v[g][2 * a + 1] = col_lo[off[a] + g * WPE];
+                        }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < NCY; ++a) {
+                            if (oky[a]) sum += v[g][2 * a];
+                            if (oky[a] && two_x) sum += v[g][2 * a + 1];
+                        }
+                        if (rowok) patch[(g * PY + Y) * PX + ccol] = sum;
+                    }
                 }
             }
         }
+        CDL_TL();
     }
+#undef CDL_TL
 }
 
 // out[n,c,d,Y,X] = (mask ? mask : 1) * alpha * (sum over depth taps kd and covering tiles of the patches) - (sub ? sub : 0)
@@ -790,8 +855,11 @@ int launch_p(const GParams &p, const Plan &pl, int mode, hipStream_t st)
     return launch_g<P, 7>(p, pl, mode, st);
 }
 
+std::atomic<unsigned long long *> g_timeline{nullptr};
+
 int dispatch(const cdl_geom *g, GParams &p, const Plan &pl, int mode, int precision, hipStream_t st)
 {
+    p.tl = g_timeline.load();
     p.rev = (precision >> 4) & 1;
     p.dbg = cdl_opts().fused_debug;
     if ((precision >> 5) != 0) return CDL_EINVAL;
@@ -830,6 +898,14 @@ int prep_pairs(const cdl_geom *g, const Plan &pl, const float *const *w1, const 
 }  // namespace
 
 extern "C" {
+
+/* Profiling hook: while buf != NULL every fused generic stage launch records s_memtime stamps of workgroup 0 into
+ * buf[wave][256] (8 x 256 x 8 bytes of device memory); tools/timeline_fusedg.py names the stamps.  NULL switches it off. */
+int cdl_fusedg_set_timeline(void *buf)
+{
+    g_timeline.store(static_cast<unsigned long long *>(buf));
+    return 0;
+}
 
 int cdl_fusedg_supported(const cdl_geom *g)
 {

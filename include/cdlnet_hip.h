@@ -370,6 +370,9 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
  * Codes in the reference's (N,M,D,H,W) layout; map = (N,4,D,H,W) words as cdl_fused2d_support_map describes.
  * precision: 0 (split-bf16 x3) only; CDL_TILES_REVERSED may be OR-ed in. */
 int cdl_fusedg_supported(const cdl_geom *g);
+/* Profiling hook (not part of the reference surface): while buf != NULL every cdl_fusedg stage launch records
+ * s_memtime stamps of its workgroup 0 into buf[8 waves][256] (16 KB of device memory).  NULL switches it off. */
+int cdl_fusedg_set_timeline(void *buf);
 size_t cdl_fusedg_frag_bytes(const cdl_geom *g);           /* bytes of one prepared (A_k, B_next) pair */
 size_t cdl_fusedg_patch_floats(const cdl_geom *g);
 size_t cdl_fusedg_tiles(const cdl_geom *g);                /* workgroup tiles (= dtau_partial rows) per launch */
