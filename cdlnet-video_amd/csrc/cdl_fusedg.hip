@@ -425,29 +425,48 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             for (int R = 0; R < MT; ++R)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-#pragma unroll 2
-            for (int ks = 0; ks < KS; ++ks) {
-                if (p.dbg & 2) { acc[0][0] += (float)ks; continue; }
+            // Software pipeline, depth 2, everything static (KS is a compile-time constant): the im2col operand and the
+            // weight fragments of k-step ks+1 are read from LDS into the OTHER register set while the matrix pipe works on
+            // k-step ks, and the products alternate between the accumulator tiles.  (Rolled, with one register set, every
+            // k-step was  table read -> wait -> 16 gathers -> wait -> fragments -> wait -> 3 dependent MFMAs -> ...:
+            // 940 cycles per k-step for 192 cycles of matrix work, tools/timeline_fusedg.py.)
+            auto gather_b = [&](int ks, bf16x8 &bh, bf16x8 &bl) {
                 const int4 o0 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h);
                 const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
                 const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-                bf16x8 bh, bl;
                 // one address add per tap; the lo plane is the same address + a constant that fits the DS offset field
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const unsigned char *pt = smem + (oo[i] + pixbase);
                     bh[i] = *reinterpret_cast<const __bf16 *>(pt);
-                    if (PREC == 0) bl[i] = *reinterpret_cast<const __bf16 *>(pt + lo_delta);
+                    bl[i] = *reinterpret_cast<const __bf16 *>(pt + lo_delta);
                 }
+            };
+            if (!(p.dbg & 2)) {
+                bf16x8 bh[2], bl[2], ah[2][MT], al[2][MT];
+                gather_b(0, bh[0], bl[0]);
 #pragma unroll
                 for (int R = 0; R < MT; ++R) {
-                    const bf16x8 ah = afrag(R * KS + ks);
-                    if (PREC == 0) {
-                        const bf16x8 al = afrag(OFF_AL + R * KS + ks);
-                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
-                        acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
+                    ah[0][R] = afrag(R * KS);
+                    al[0][R] = afrag(OFF_AL + R * KS);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cu = ks & 1, nx = cu ^ 1;
+                    if (ks + 1 < KS) {
+                        gather_b(ks + 1, bh[nx], bl[nx]);
+#pragma unroll
+                        for (int R = 0; R < MT; ++R) {
+                            ah[nx][R] = afrag(R * KS + ks + 1);
+                            al[nx][R] = afrag(OFF_AL + R * KS + ks + 1);
+                        }
                     }
-                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cu][R], bh[cu], acc[R], 0, 0, 0);
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cu][R], bl[cu], acc[R], 0, 0, 0);
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cu][R], bh[cu], acc[R], 0, 0, 0);
                 }
             }
 
