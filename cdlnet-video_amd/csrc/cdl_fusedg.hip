@@ -435,6 +435,8 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
                 const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 // one address add per tap; the lo plane is the same address + a constant that fits the DS offset field
+                // (ds_read_u16_d16 / _d16_hi would save the v_perm_b32 per pair, but with SRAM ECC -- gfx950 -- a d16 load
+                //  zeroes the other half of the register instead of keeping it: tried through inline asm, wrong results)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const unsigned char *pt = smem + (oo[i] + pixbase);
@@ -442,31 +444,46 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                     bl[i] = *reinterpret_cast<const __bf16 *>(pt + lo_delta);
                 }
             };
-            if (!(p.dbg & 2)) {
-                bf16x8 bh[2], bl[2], ah[2][MT], al[2][MT];
+
+            {
+                // (the im2col operand is double-buffered; the weight fragments only where the groups' col2im rings leave
+                //  the registers: G * P <= 21)
+                constexpr int FS = G * P <= 21 ? 2 : 1;
+                bf16x8 bh[2], bl[2], ah[FS][MT], al[FS][MT];
                 gather_b(0, bh[0], bl[0]);
+                if (FS == 2) {
 #pragma unroll
-                for (int R = 0; R < MT; ++R) {
-                    ah[0][R] = afrag(R * KS);
-                    al[0][R] = afrag(OFF_AL + R * KS);
+                    for (int R = 0; R < MT; ++R) {
+                        ah[0][R] = afrag(R * KS);
+                        al[0][R] = afrag(OFF_AL + R * KS);
+                    }
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int cu = ks & 1, nx = cu ^ 1;
-                    if (ks + 1 < KS) {
-                        gather_b(ks + 1, bh[nx], bl[nx]);
+                    const int cu = ks & 1, nx = cu ^ 1, fc = FS == 2 ? cu : 0, fn = FS == 2 ? nx : 0;
+                    if (FS == 1) {
 #pragma unroll
                         for (int R = 0; R < MT; ++R) {
-                            ah[nx][R] = afrag(R * KS + ks + 1);
-                            al[nx][R] = afrag(OFF_AL + R * KS + ks + 1);
+                            ah[0][R] = afrag(R * KS + ks);
+                            al[0][R] = afrag(OFF_AL + R * KS + ks);
+                        }
+                    }
+                    if (ks + 1 < KS) {
+                        gather_b(ks + 1, bh[nx], bl[nx]);
+                        if (FS == 2) {
+#pragma unroll
+                            for (int R = 0; R < MT; ++R) {
+                                ah[fn][R] = afrag(R * KS + ks + 1);
+                                al[fn][R] = afrag(OFF_AL + R * KS + ks + 1);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cu][R], bh[cu], acc[R], 0, 0, 0);
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fc][R], bh[cu], acc[R], 0, 0, 0);
 #pragma unroll
-                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cu][R], bl[cu], acc[R], 0, 0, 0);
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fc][R], bl[cu], acc[R], 0, 0, 0);
 #pragma unroll
-                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cu][R], bh[cu], acc[R], 0, 0, 0);
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fc][R], bh[cu], acc[R], 0, 0, 0);
                 }
             }
 
@@ -544,29 +561,31 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                     zh[q][e] = hh;
                     if (PREC == 0) zl[q][e] = (__bf16)(val - (float)hh);
                 }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                // One 32-row tap tile at a time (P = 7: filter rows 0-3 live in tile 0, rows 4-6 in tile 1), so only one
-                // accumulator tile is live.  col2im, column direction: for filter row i, sum over j of tap (i, j) shifted
-                // right by j lanes; lane L (0 .. 32+P-2) ends with the contribution to output column x0 - HALO + L.  The
-                // rows of a tile run as independent Horner chains side by side (no DPP wait states to pad); taps that sit
-                // in the upper lane half are fetched with one cross-lane read each.  Row direction: tap row i of image
-                // row y lands on output row y - HALO + i = ring slot i.
-#pragma unroll
-                for (int Rt = 0; Rt < RT; ++Rt) {
+            // One 32-row tap tile at a time (P = 7: filter rows 0-3 live in tile 0, rows 4-6 in tile 1).  col2im, column
+            // direction: for filter row i, sum over j of tap (i, j) shifted right by j lanes; lane L (0 .. 32+P-2) ends with
+            // the contribution to output column x0 - HALO + L.  The rows of a tile run as independent Horner chains side by
+            // side (no DPP wait states to pad); taps that sit in the upper lane half are fetched with one cross-lane read
+            // each.  Row direction: tap row i of image row y lands on output row y - HALO + i = ring slot i.
+            // The tap tiles t = g * RT + Rt form a depth-2 pipeline: the products of tile t+1 are issued (into the other
+            // accumulator) before the col2im of tile t, so the matrix pipe works under the DPP chains; the number of
+            // 16-channel k-steps is a compile-time constant inside (two instantiations under one uniform branch).
+            auto synth = [&](auto nq_c) {
+                constexpr int NQ = decltype(nq_c)::value;
+                constexpr int NTT = G * RT;
+                auto mm = [&](int t) {
                     f32x16 Dt = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int q = 0; q < 2 * MT; ++q) {
-                        if (q >= KQ) break;                  // uniform: channels beyond M
-                        const int f = (g * RT + Rt) * KQ + q;
-                        const bf16x8 wh = bfrag(f);
-                        if (PREC == 0) {
-                            const bf16x8 wl = bfrag(OFF_BL + f);
-                            Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt, 0, 0, 0);
-                            Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt, 0, 0, 0);
-                        }
+                    for (int q = 0; q < NQ; ++q) {
+                        const int f = t * NQ + q;
+                        const bf16x8 wh = bfrag(f), wl = bfrag(OFF_BL + f);
+                        Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt, 0, 0, 0);
+                        Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt, 0, 0, 0);
                         Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh[q], Dt, 0, 0, 0);
                     }
+                    return Dt;
+                };
+                auto c2i = [&](int t, const f32x16 &Dt) {
+                    const int g = t / RT, Rt = t % RT;
                     float sr[P];
 #pragma unroll
                     for (int i = 0; i < P; ++i) sr[i] = 0.0f;
@@ -585,13 +604,32 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
 #pragma unroll
                     for (int i = 0; i < P; ++i)
                         if ((tap_slot<P>(i, 0) >> 5) == Rt) ring[g][i] += sr[i];
-                }
-                // ring slot 0 is complete after this block: one plain LDS store per lane into the wave's own patch
-                if (lane < WPW) wp[g * WPE + b * WPW + lane] = ring[g][0];
+                    if (Rt == RT - 1) {
+                        // ring slot 0 is complete: one plain LDS store per lane into the wave's own patch
+                        if (lane < WPW) wp[g * WPE + b * WPW + lane] = ring[g][0];
 #pragma unroll
-                for (int i = 0; i + 1 < P; ++i) ring[g][i] = ring[g][i + 1];
-                ring[g][P - 1] = 0.0f;
-            }
+                        for (int i = 0; i + 1 < P; ++i) ring[g][i] = ring[g][i + 1];
+                        ring[g][P - 1] = 0.0f;
+                    }
+                };
+                // (the reverse mode of the 5-group shapes keeps 32 threshold-gradient registers besides the rings: the
+                //  second accumulator tile spills there and costs more than it hides -- cfg3 fwd+bwd 10.2 vs 10.7 ms)
+                constexpr bool SPIPE = !(MODE == MODE_BWD && G * P > 21);
+                f32x16 D[2];
+                D[0] = mm(0);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    if (SPIPE) {
+                        if (t + 1 < NTT) D[(t + 1) & 1] = mm(t + 1);
+                        c2i(t, D[t & 1]);
+                    } else {
+                        c2i(t, D[0]);
+                        if (t + 1 < NTT) D[0] = mm(t + 1);
+                    }
+                }
+            };
+            if (KQ == 2 * MT) synth(std::integral_constant<int, 2 * MT>{});      // uniform
+            else synth(std::integral_constant<int, 2 * MT - 1>{});
             CDL_TL();
         }
         // ---- the P-1 output rows below the wave's last image row are still in the ring
