@@ -116,24 +116,43 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
         for (int R = 0; R < MT; ++R)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-#pragma unroll 1
-        for (int ks = 0; ks < KS; ++ks) {
+        // depth-2 software pipeline over the k-steps: the im2col operand of k-step ks+1 is gathered into the other
+        // register set before the products of ks are issued, and the products alternate between the accumulator tiles
+        // (rolled with one register set every k-step was table read -> gathers -> fragments -> dependent MFMAs in
+        // series; the same change took cdl_fusedg.hip's analysis from 940 to 650 cycles per k-step)
+        auto gather_b = [&](int ks, bf16x8 &bh, bf16x8 &bl) {
             const int4 o0 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h);
             const int4 o1 = *reinterpret_cast<const int4 *>(koff + 16 * ks + 8 * h + 4);
             const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-            bf16x8 bh, bl;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 bh[i] = xh[oo[i] + pixbase];
                 bl[i] = xl[oo[i] + pixbase];
             }
+        };
+        auto products = [&](int ks, const bf16x8 &bh, const bf16x8 &bl) {
+            bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int R = 0; R < MT; ++R) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 0) * 64 + lane]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 1) * 64 + lane]);
-                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[R], 0, 0, 0);
-                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[R], 0, 0, 0);
-                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[R], 0, 0, 0);
+                ah[R] = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 0) * 64 + lane]);
+                al[R] = __builtin_bit_cast(bf16x8, wl[((R * KS + ks) * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+            for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[R], bh, acc[R], 0, 0, 0);
+#pragma unroll
+            for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bl, acc[R], 0, 0, 0);
+#pragma unroll
+            for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[R], bh, acc[R], 0, 0, 0);
+        };
+        {
+            bf16x8 bh0, bl0, bh1, bl1;
+            gather_b(0, bh0, bl0);
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ks += 2) {
+                if (ks + 1 < KS) gather_b(ks + 1, bh1, bl1);      // uniform branches
+                products(ks, bh0, bl0);
+                if (ks + 2 < KS) gather_b(ks + 2, bh0, bl0);
+                if (ks + 1 < KS) products(ks + 1, bh1, bl1);
             }
         }
         // epilogue through LDS, one 32-channel accumulator tile at a time: the waves park tile R as [channel][pixel]
