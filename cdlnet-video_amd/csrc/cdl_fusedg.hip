@@ -244,9 +244,17 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
     {
         uint4 *wdst = reinterpret_cast<uint4 *>(smem);
         if (PREC == 0) {
-            for (int i = tid; i < 2 * FA * 64; i += NT) wdst[i] = p.frags[i];
-            uint4 *bdst = reinterpret_cast<uint4 *>(smem + cv.wb);
-            for (int i = tid; i < 2 * FB * 64; i += NT) bdst[i] = p.frags[2 * FA * 64 + i];
+            // (A and B fragments are contiguous in the prepared list and in LDS: one copy, 4 loads in flight per thread --
+            //  one load -> store at a time took 13k cycles per workgroup, 4 % of a cfg3 launch)
+            const int nfr = 2 * (FA + FB) * 64;
+            for (int i = tid; i < nfr; i += 4 * NT) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p.frags[min(i + u * NT, nfr - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u * NT < nfr) wdst[i + u * NT] = v[u];
+            }
         } else {                                             // plain bf16: hi parts only
             for (int i = tid; i < FA * 64; i += NT) wdst[i] = p.frags[i];
             uint4 *bdst = reinterpret_cast<uint4 *>(smem + cv.wb);
