@@ -547,23 +547,44 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         __builtin_amdgcn_sched_barrier(0);   // phase fences: keep the scheduler from hoisting every LDS
                                              // weight read of the block to its top (register blow-up)
         // -- analysis-like GEMM (weights from LDS)
+        // k-step outer, channel tile inner: the fragments of one k-step (all tiles) are read together, the products
+        // alternate between the accumulator tiles, and the next k-step's fragments are read while they issue.  (Tile
+        // outer / k-step inner was 12 dependent products per accumulator, each fragment read followed by a full LDS
+        // wait: cdl_fusedg.hip's timeline study)
         f32x16 acc[MT];
 #pragma unroll
-        for (int R = 0; R < MT; ++R) {
+        for (int R = 0; R < MT; ++R)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-            if (p.dbg & 4) { acc[R][0] = (float)rh[0][0] + (float)rl[1][1]; continue; }
+        if (p.dbg & 4) {
+#pragma unroll
+            for (int R = 0; R < MT; ++R) acc[R][0] = (float)rh[0][0] + (float)rl[1][1];
+        } else {
+            bf16x8 wh[2][MT], wlo[2][MT];
+#pragma unroll
+            for (int R = 0; R < MT; ++R) {
+                wh[0][R] = wfrag(OFF_AH + R * 4);
+                if (PREC == 0) wlo[0][R] = wfrag(OFF_AL + R * 4);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 wh = wfrag(OFF_AH + R * 4 + ks);
-                if (PREC == 0) {
-                    const bf16x8 wlo = wfrag(OFF_AL + R * 4 + ks);
-                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, rh[ks], acc[R], 0, 0, 0);
-                    acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rl[ks], acc[R], 0, 0, 0);
+                const int cu = ks & 1, nx = cu ^ 1;
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) {
+                        wh[nx][R] = wfrag(OFF_AH + R * 4 + ks + 1);
+                        if (PREC == 0) wlo[nx][R] = wfrag(OFF_AL + R * 4 + ks + 1);
+                    }
                 }
-                acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rh[ks], acc[R], 0, 0, 0);
+                if (PREC == 0) {
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[cu][R], rh[ks], acc[R], 0, 0, 0);
+#pragma unroll
+                    for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cu][R], rl[ks], acc[R], 0, 0, 0);
+                }
+#pragma unroll
+                for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cu][R], rh[ks], acc[R], 0, 0, 0);
             }
-            if (MODE == MODE_BWD) __builtin_amdgcn_sched_barrier(0);     // bound the weight-read hoisting
         }
 
         __builtin_amdgcn_sched_barrier(0);
@@ -630,10 +651,25 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         for (int Rp = 0; Rp < 2; ++Rp)
 #pragma unroll
             for (int v = 0; v < 16; ++v) D[Rp][v] = 0.0f;
+        {
+            // 16-channel k-steps q = 2R + s; the weight fragments of step q+1 (both tap tiles) are read while the products
+            // of step q issue, and the products alternate between the two tap tiles
+            bf16x8 bwh[2][2], bwl[2][2];
 #pragma unroll
-        for (int R = 0; R < MT; ++R)
+            for (int Rp = 0; Rp < 2; ++Rp) {
+                bwh[0][Rp] = wfrag(OFF_BH + Rp * 2 * MT);
+                if (PREC == 0) bwl[0][Rp] = wfrag(OFF_BL + Rp * 2 * MT);
+            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int q = 0; q < 2 * MT; ++q) {
+                const int R = q >> 1, s = q & 1, cu = q & 1, nx = cu ^ 1;
+                if (q + 1 < 2 * MT) {
+#pragma unroll
+                    for (int Rp = 0; Rp < 2; ++Rp) {
+                        bwh[nx][Rp] = wfrag(OFF_BH + Rp * 2 * MT + q + 1);
+                        if (PREC == 0) bwl[nx][Rp] = wfrag(OFF_BL + Rp * 2 * MT + q + 1);
+                    }
+                }
                 bf16x8 zh, zl;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -642,17 +678,18 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     zh[jj] = hh;
                     if (PREC == 0 && LOUT != LAY_BLK16) zl[jj] = (__bf16)(val - (float)hh);   // a bf16-stored code has no lo part
                 }
+                if (PREC == 0) {
 #pragma unroll
-                for (int Rp = 0; Rp < 2; ++Rp) {
-                    const bf16x8 wh = wfrag(OFF_BH + Rp * 2 * MT + 2 * R + s);
-                    if (PREC == 0) {
-                        const bf16x8 wlo = wfrag(OFF_BL + Rp * 2 * MT + 2 * R + s);
-                        D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, zh, D[Rp], 0, 0, 0);
-                        if (LOUT != LAY_BLK16) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl, D[Rp], 0, 0, 0);
+                    for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwl[cu][Rp], zh, D[Rp], 0, 0, 0);
+                    if (LOUT != LAY_BLK16) {
+#pragma unroll
+                        for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwh[cu][Rp], zl, D[Rp], 0, 0, 0);
                     }
-                    D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh, D[Rp], 0, 0, 0);
                 }
+#pragma unroll
+                for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwh[cu][Rp], zh, D[Rp], 0, 0, 0);
             }
+        }
 
         __builtin_amdgcn_sched_barrier(0);
         // -- col2im, row direction: tap row i = 4Rp + (v>>2) of image row y lands on halo row yl + i;
