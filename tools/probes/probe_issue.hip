@@ -19,8 +19,10 @@ __global__ __launch_bounds__(512) void k_issue(float *out, long long *cycles, in
     f32x16 acc[4];
     for (int a = 0; a < 4; ++a)
         for (int v = 0; v < 16; ++v) acc[a][v] = 0.0f;
-    bf16x8 x, y;
-    for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(0.001f * (threadIdx.x + i)); y[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
+    bf16x8 x[4], y;                      // a different operand per accumulator: identical products would be merged
+    for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 8; ++i) x[a][i] = (__bf16)(0.001f * (threadIdx.x + i + 3 * a));
+    for (int i = 0; i < 8; ++i) y[i] = (__bf16)(0.002f * (threadIdx.x - i));
     float f[16];
     for (int i = 0; i < 16; ++i) f[i] = 0.5f + 0.01f * (threadIdx.x + i);
     const float m = 0.999f, c = 0.001f;
@@ -29,10 +31,10 @@ __global__ __launch_bounds__(512) void k_issue(float *out, long long *cycles, in
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < (NM > NV / 8 ? NM : NV / 8); ++k) {       // interleave: 1 MFMA, then 8 VALU, ...
-            if (k < NM) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[k & 3], 0, 0, 0);
+            if (k < NM) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[k & 3], y, acc[k & 3], 0, 0, 0);
             if (k < NV / 8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[(8 * k + j) & 15] = __builtin_fmaf(f[(8 * k + j) & 15], m, c);
+                for (int j = 0; j < 8; ++j) f[(8 * k + j) & 15] = __builtin_amdgcn_fmed3f(f[(8 * k + j) & 15] + c, m, c);
             }
         }
     }
