@@ -14,6 +14,7 @@ SHAPES = [
     (2, 1, 24, (3, 17, 33), (3, 3, 3), False),        # P = 3, M not a multiple of 16
     (1, 1, 8, (40, 72), (5, 5), False),               # small M, 2-D, one group
     (1, 1, 64, (4, 16, 64), (3, 7, 7), True),         # Pd = 3 with 7 x 7 planes
+    (1, 1, 16, (2, 20, 36), (5, 5, 5), False),        # fewer frames than depth taps: most planes of a tile are absent
 ]
 
 
