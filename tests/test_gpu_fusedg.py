@@ -173,3 +173,37 @@ def test_fusedg_assemble_vector_form_is_bit_identical(hip_env):
             hip_env("CDL_FUSED_DEBUG", dbg)
             outs.append((o.fusedg_assemble(g, patches, mask, yp, 1.0), o.fusedg_assemble(g, patches, None, None, -1.0)))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fusedg_timeline_hook_records_and_does_not_disturb(hip_env):
+    """cdl_fusedg_set_timeline: with a buffer registered a stage launch stamps increasing s_memtime values for every
+    wave of workgroup 0 and computes the same bits; unregistered, nothing is written."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    g = make_geom(1, 1, 48, (4, 32, 64), (5, 5, 5))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    r = torch.randn(g.image_shape(), device="cuda", generator=gen)
+    z = torch.randn(g.code_shape(), device="cuda", generator=gen)
+    w = torch.randn(g.filter_shape(), device="cuda", generator=gen) * 0.05
+    tau = torch.full((1, 48), 0.3, device="cuda")
+    frags = o.fusedg_prep(g, w, w)
+    patches = o.fusedg_patches(g, "cuda")
+    ref = o.fusedg_iter(g, r, z, tau, frags, -1.0, patches).clone()
+    pref = patches.clone()
+    tl = torch.zeros(8 * 256, dtype=torch.int64, device="cuda")
+    lib = cva._lib.lib()
+    try:
+        lib.cdl_fusedg_set_timeline(tl.data_ptr())
+        got = o.fusedg_iter(g, r, z, tau, frags, -1.0, patches).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.cdl_fusedg_set_timeline(None)
+    assert torch.equal(got, ref) and torch.equal(patches, pref)
+    t = tl.view(8, 256).cpu()
+    n = int((t[0] > 0).sum())
+    assert n >= 21                                               # kernel start + 20 stamps of the first tile
+    assert bool((t[:, 1:n] >= t[:, :n - 1]).all())
+    tl.zero_()
+    o.fusedg_iter(g, r, z, tau, frags, -1.0, patches)
+    torch.cuda.synchronize()
+    assert int(tl.abs().sum()) == 0

@@ -189,3 +189,19 @@ def test_csr_modules_surface():
                            "model": {"adaptive": True, "K": 2, "M": 5, "C": 1, "P": 9, "s": 2, "t0": 0,
                                      "init": True}})
     assert isinstance(net, cva.CDLNet_CSRf2) and net.g1.shape == (2, 2, 5, 1, 1)
+
+
+def test_awgn_generator_reproduces_the_reference_noise_stream():
+    """utils.py:29-41 draws `rand(N,1,1,1)` for sigma and then `randn_like(input)` from the global generator; with
+    `generator=torch.default_generator` the product draws the same numbers in the same order (what lets a GPU run
+    replay a CPU reference run, tests/test_gpu_trainer.py)."""
+    x = torch.rand(3, 1, 6, 5)
+    torch.manual_seed(11)
+    sigma = 20 + (30 - 20) * torch.rand(len(x), 1, 1, 1)
+    want = x + torch.randn_like(x) * (sigma / 255)
+    torch.manual_seed(11)
+    got, s = cva.utils.awgn(x, (20, 30), torch.default_generator)
+    assert torch.equal(got, want) and torch.equal(s, sigma)
+    torch.manual_seed(11)
+    got2, s2 = cva.utils.awgn(x, (20, 30))                     # no generator: the input's device default, same stream on CPU
+    assert torch.equal(got2, want) and torch.equal(s2, sigma)
