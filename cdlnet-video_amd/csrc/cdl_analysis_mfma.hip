@@ -62,6 +62,8 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     __bf16 *xh = reinterpret_cast<__bf16 *>(koff + KS * 16);                          // [NP][PS] hi
     __bf16 *xl = xh + (size_t)NP * PS;                                                // [NP][PS] lo
     float *stage = reinterpret_cast<float *>(xh);          // [32][ALX*ALY] epilogue staging, reuses the planes (32 KB)
+    const size_t plane_bytes = (size_t)NP * PS * 4 > (size_t)32 * ALX * ALY * 4 ? (size_t)NP * PS * 4 : (size_t)32 * ALX * ALY * 4;
+    float *tau_s = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(xh) + plane_bytes);   // [32 MT] thresholds
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
     const int K = NP * PH * PW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -88,6 +90,15 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     const int txg = b % ((tilesX + TPW - 1) / TPW); b /= (tilesX + TPW - 1) / TPW;
     const int ty = b % tilesY; b /= tilesY;
     const int zd = b % Dz, n = b / Dz;
+    // thresholds of this workgroup's channels (one sample, MT channel tiles): read once into LDS -- the epilogue read
+    // tau[row] from global memory per element (a third of its memory instructions) -- and a workgroup-uniform flag
+    // selects the clamp form of the shrinkage when none is negative (cdl_fused2d.hip)
+    if (tau && threadIdx.x < 32 * MT) {
+        const int m = 32 * r0 + threadIdx.x;
+        tau_s[threadIdx.x] = m < g.M ? tau[(size_t)n * g.M + m] : 0.0f;
+    }
+    __syncthreads();
+    const bool tau_neg = tau && __syncthreads_or(threadIdx.x < 32 * MT && tau_s[threadIdx.x] < 0.0f);
     const size_t slab = (size_t)Dz * Hz * Wz;
     const int pixbase = (wv * SW) * XW + l32 * SW;
 
@@ -167,36 +178,41 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
             for (int v = 0; v < 16; ++v)
                 stage[(8 * (v >> 2) + 4 * h + (v & 3)) * (ALX * ALY) + wv * ALX + l32] = acc[R][v];
             __syncthreads();
-            // 16 values per thread in two batches of 8 whose loads are issued together (predicated, not branched:
-            // with one tile per CU nothing else hides their latency); 32-bit offsets inside the sample's block
+            // 16 values per thread in two batches of 8 whose loads are issued together (predicated, not branched);
+            // 32-bit offsets inside the sample's block.  A thread keeps its PIXEL (element e = tid + 512 jj is channel
+            // 2 jj + (tid >> 8) of pixel tid & 255), so everything but the channel stride is computed once per tile.
+            static_assert(ANT == 2 * ALX * ALY, "thread <-> (channel parity, pixel) mapping");
             constexpr int NB = 8;
             const float *zin_n = zin ? zin + nbase : nullptr;
             const float *gate_n = (zin && gate) ? gate + nbase : nullptr;
             float *out_n = out + nbase;
+            const int pxl = threadIdx.x & (ALX * ALY - 1), chh = threadIdx.x >> 8;
+            const int oy = ty * ALY + pxl / ALX, ox = tx * ALX + pxl % ALX;
+            const bool okp = oy < Hz && ox < Wz;
+            const int m0 = 32 * (r0 + R) + chh;
+            const int idx0 = m0 * (int)slab + oy * Wz + ox, step = 2 * (int)slab;
 #pragma unroll 1
             for (int j0 = 0; j0 < 32 * ALX * ALY / ANT; j0 += NB) {
                 float bv[NB], gv[NB];
                 int ix[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int e = threadIdx.x + (j0 + j) * ANT;
-                    const int ch = e / (ALX * ALY), pxl = e % (ALX * ALY);
-                    const int m = 32 * (r0 + R) + ch, oy = ty * ALY + pxl / ALX, ox = tx * ALX + pxl % ALX;
-                    const bool ok = m < g.M && oy < Hz && ox < Wz;
-                    ix[j] = ok ? m * (int)slab + oy * Wz + ox : -1;
+                    const bool ok = okp && m0 + 2 * (j0 + j) < g.M;
+                    ix[j] = ok ? idx0 + (j0 + j) * step : -1;
                     bv[j] = zin_n ? zin_n[ok ? ix[j] : 0] : 0.0f;
                     gv[j] = gate_n ? gate_n[ok ? ix[j] : 0] : 1.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int e = threadIdx.x + (j0 + j) * ANT;
-                    const int m = min(32 * (r0 + R) + e / (ALX * ALY), g.M - 1);
+                    const int m = min(m0 + 2 * (j0 + j), g.M - 1);
                     const float base = gv[j] == 0.0f ? 0.0f : bv[j];
                     const float u = fmaf(alpha, stage[e], base);
                     const int row = n * g.M + m;
+                    const float ts = tau_s[32 * R + chh + 2 * (j0 + j)];     // (unused when tau == nullptr)
                     if (ix[j] >= 0)
                         out_n[ix[j]] = PROX ? cdl_prox_apply(px, u, nbase + ix[j], row)
-                                            : (tau ? cdl_shrink(u, tau[row]) : u);
+                                            : (tau ? (tau_neg ? cdl_shrink(u, ts) : u - __builtin_amdgcn_fmed3f(u, -ts, ts)) : u);
                 }
             }
         }
@@ -229,7 +245,7 @@ bool plan_for(const cdl_geom *g, Plan *p)
     const size_t PS = ((XH * XW + 7) / 8) * 8;
     size_t planes = (size_t)g->C * g->Pd * PS * 2 * 2;
     if (planes < 32 * ALX * ALY * 4) planes = 32 * ALX * ALY * 4;          // the epilogue staging reuses them
-    p->lds = (size_t)p->MTW * p->KS * 2 * 64 * 16 + (size_t)p->KS * 16 * 4 + planes;
+    p->lds = (size_t)p->MTW * p->KS * 2 * 64 * 16 + (size_t)p->KS * 16 * 4 + planes + (size_t)32 * p->MTW * 4;
     if (p->lds > 96 * 1024) return false;
     if (p->groups < 96 || p->groups >= ((size_t)1 << 31)) return false;    // small launches: the VALU kernels do better
     return true;
