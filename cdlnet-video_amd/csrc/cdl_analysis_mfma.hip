@@ -182,7 +182,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
             // 32-bit offsets inside the sample's block.  A thread keeps its PIXEL (element e = tid + 512 jj is channel
             // 2 jj + (tid >> 8) of pixel tid & 255), so everything but the channel stride is computed once per tile.
             static_assert(ANT == 2 * ALX * ALY, "thread <-> (channel parity, pixel) mapping");
-            constexpr int NB = 8;
+            constexpr int NB = PROX ? 8 : 16;               // (the CSR maps need their registers: 16 in flight spills there)
             const float *zin_n = zin ? zin + nbase : nullptr;
             const float *gate_n = (zin && gate) ? gate + nbase : nullptr;
             float *out_n = out + nbase;
