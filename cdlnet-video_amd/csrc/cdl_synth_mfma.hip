@@ -61,7 +61,8 @@ __global__ void k_synth_prep(const float *__restrict__ w, uint4 *__restrict__ fr
 template <int PH, int PW, int SW, int KSM>
 __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__restrict__ z,
                                                  const float *__restrict__ gate, const uint4 *__restrict__ frags,
-                                                 float *__restrict__ patches, int tilesX, int tilesY, int KS, int KCH)
+                                                 float *__restrict__ patches, int tilesX, int tilesY, int KS, int KCH,
+                                                 int ntiles)
 {
     constexpr int T = PH * PW, RT = (T + 31) / 32;
     constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
@@ -70,17 +71,28 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
     uint4 *wl = reinterpret_cast<uint4 *>(smem + (size_t)RT * 32 * TCX * TCY * 4);   // [RT][KCH][2][64]: KCH k-steps of
                                                             // weight fragments at a time (all KS when they fit)
     const int Dz = g.D / g.sd, Hz = g.H / g.sh, Wz = g.W / g.sw;
-    int b = blockIdx.x;
-    const int tx = b % tilesX; b /= tilesX;
-    const int ty = b % tilesY; b /= tilesY;
-    const int zd = b % Dz, n = b / Dz;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c32 = lane & 31, h = lane >> 5;
     const int G = g.C * g.Pd;
     const size_t slab = (size_t)Dz * Hz * Wz;                                  // one code channel of one sample
+    const int nfr = RT * KS * 2 * 64;                                          // uint4 fragments per group
+    // Persistent workgroups (grid = min(tiles, CUs)).  With ONE group whose fragments fit LDS whole (2-D nets: the
+    // shipped M = 169 bank is 44 KB) they are loaded once per workgroup, not once per tile -- 4096 tiles x 44 KB of
+    // L2 reads and their index arithmetic per launch at the s2030 shape.
+    const bool resident = G == 1 && KCH >= KS;
+    if (resident) {
+        for (int i = threadIdx.x; i < nfr; i += SNT) {
+            const int R = i / (KS * 2 * 64), rem = i % (KS * 2 * 64);
+            wl[(size_t)R * KCH * 2 * 64 + rem] = frags[i];
+        }
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY; b /= tilesY;
+    const int zd = b % Dz, n = b / Dz;
     const size_t zbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
     const int cx = tx * TCX + c32;
-    const int nfr = RT * KS * 2 * 64;                                          // uint4 fragments per group
 
     // KSM > 0: the code values of this wave's pixel row are loaded and split ONCE (KS <= KSM k-steps in registers) and
     // reused by every (c, kd) group; KSM == 0 (many code channels): reloaded per group
@@ -122,12 +134,14 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
         for (int kc0 = 0; kc0 < KS; kc0 += KCH) {           // weight fragments of KCH k-steps at a time
             const int kcn = min(KCH, KS - kc0);
-            __syncthreads();                                // previous chunk's / group's readers are done
-            for (int i = threadIdx.x; i < RT * kcn * 2 * 64; i += SNT) {
-                const int R = i / (kcn * 2 * 64), rem = i % (kcn * 2 * 64);
-                wl[(size_t)R * KCH * 2 * 64 + rem] = frags[(size_t)grp * nfr + ((size_t)R * KS + kc0) * 2 * 64 + rem];
+            if (!resident) {
+                __syncthreads();                            // previous chunk's / group's readers are done
+                for (int i = threadIdx.x; i < RT * kcn * 2 * 64; i += SNT) {
+                    const int R = i / (kcn * 2 * 64), rem = i % (kcn * 2 * 64);
+                    wl[(size_t)R * KCH * 2 * 64 + rem] = frags[(size_t)grp * nfr + ((size_t)R * KS + kc0) * 2 * 64 + rem];
+                }
             }
-            __syncthreads();
+            __syncthreads();                                // fragments in place (resident: the one-off load, first tile)
             if (KSM > 0) {                                  // KS <= KSM: one chunk, code fragments from registers
 #pragma unroll
                 for (int q = 0; q < KSM; ++q) {
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
         }
         __syncthreads();
         // col2im into the patch of this (tile, group): fixed (ki, kj) order per output
-        float *patch = patches + ((size_t)blockIdx.x * G + grp) * (PY * PX);
+        float *patch = patches + ((size_t)tile * G + grp) * (PY * PX);
         for (int o = threadIdx.x; o < PY * PX; o += SNT) {
             const int Yl = o / PX, Xl = o % PX;
             float sum = 0.0f;
@@ -205,6 +219,7 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
             patch[o] = sum;
         }
     }
+    }   // tiles of this workgroup
 }
 
 // out[n][c][d][Y][X] = mask * alpha * sum over depth taps and covering tiles of the patches - sub
@@ -291,10 +306,12 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
     CDL_LAUNCH_CHECK();
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_synth_m<PH, PW, SW, 0>, 150 * 1024)) return rc;
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_synth_m<PH, PW, SW, 4>, 150 * 1024)) return rc;
+    const size_t cus = (size_t)cdl_cu_count();
+    const unsigned grid_m = (unsigned)(p.tiles < cus ? p.tiles : cus);      // one workgroup per CU (64-108 KB of LDS each)
     if (p.KS <= 4 && g->C * g->Pd > 1)       // several groups share the code values: keep their fragments in registers
-        k_synth_m<PH, PW, SW, 4><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH);
+        k_synth_m<PH, PW, SW, 4><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
     else
-        k_synth_m<PH, PW, SW, 0><<<(unsigned)p.tiles, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH);
+        k_synth_m<PH, PW, SW, 0><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
     CDL_LAUNCH_CHECK();
     dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
     k_synth_assemble<PH, PW, SW><<<grid, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
