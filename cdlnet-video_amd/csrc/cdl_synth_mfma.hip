@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TCX = 32, TCY = 8;      // code-pixel tile of a workgroup: 8 blocks of 32 pixels, one per wave
 constexpr int SNT = 64 * TCY;         // 8 waves: with 64-108 KB of LDS only one workgroup fits a CU
+constexpr int OOB = 0x7fff0000;       // a vector offset beyond any descriptor: the load returns 0
 constexpr int KSC = 4;                // k-steps whose code values are loaded together (32 loads in flight per lane)
 
 // ------------------------------------------------------------------------------------------
@@ -55,6 +56,15 @@ __global__ void k_synth_prep(const float *__restrict__ w, uint4 *__restrict__ fr
     const size_t base = (((size_t)g * RT + R) * KS + ks) * 2;
     frags[(base + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
     frags[(base + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+// buffer descriptor over [base, base + bytes) with the base made provably wave-uniform (otherwise every access gets a
+// waterfall loop, cdl_fused2d.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base, size_t bytes)
+{
+    const size_t a = reinterpret_cast<size_t>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -91,29 +101,42 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
     const int tx = b % tilesX; b /= tilesX;
     const int ty = b % tilesY; b /= tilesY;
     const int zd = b % Dz, n = b / Dz;
-    const size_t zbase = (size_t)n * g.M * slab + (size_t)zd * Hz * Wz;
     const int cx = tx * TCX + c32;
+    // fat operand through buffer descriptors of the sample's code block (< 2 GB, plan_for): the channel travels in the
+    // SCALAR offset (16 ks + i planes), the lane's part -- pixel and channel half 8h -- in the vector offset, so a
+    // load costs no address arithmetic (64-bit pointer math per element was a quarter of the kernel's VALU work at
+    // M = 169).  Only the vector offset is range-checked: channels beyond M are masked per lane in the last k-step.
+    const size_t sbase = (size_t)n * g.M * slab;
+    const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(z + sbase, (size_t)g.M * slab * 4);
+    const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(gate ? gate + sbase : z + sbase, (size_t)g.M * slab * 4);
+    const int slab4 = (int)slab * 4;
 
     // KSM > 0: the code values of this wave's pixel row are loaded and split ONCE (KS <= KSM k-steps in registers) and
     // reused by every (c, kd) group; KSM == 0 (many code channels): reloaded per group
     const int blk = wv;                                     // code row of this wave's block inside the tile
     const int cy = ty * TCY + blk;
     const bool ok = cy < Hz && cx < Wz;
-    const size_t poff = zbase + (size_t)(ok ? cy : 0) * Wz + (ok ? cx : 0);
+    const int voff = ok ? (int)(((size_t)(8 * h) * slab + (size_t)zd * Hz * Wz + (size_t)cy * Wz + cx) * 4) : OOB;
+    auto load8 = [&](int ks, float (&zv)[8]) {               // channels 16 ks + 8 h + (0..7) of this lane's pixel
+        const int soff0 = __builtin_amdgcn_readfirstlane(16 * ks * slab4);
+        const bool tail = 16 * ks + 16 > g.M;                // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int vo = (tail && 16 * ks + 8 * h + i >= g.M) ? OOB : voff;
+            float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, soff0 + i * slab4, 0));
+            if (gate) {
+                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vo, soff0 + i * slab4, 0));
+                if (gv == 0.0f) v = 0.0f;
+            }
+            zv[i] = v;
+        }
+    };
     bf16x8 cbh[KSM > 0 ? KSM : 1], cbl[KSM > 0 ? KSM : 1];
     if (KSM > 0) {
 #pragma unroll
         for (int q = 0; q < KSM; ++q) {
             float zv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = 16 * q + 8 * h + i;
-                const bool live = ok && m < g.M;
-                const size_t idx = poff + (size_t)(live ? m : 0) * slab;
-                float v = z[idx];
-                if (gate && gate[idx] == 0.0f) v = 0.0f;
-                zv[i] = live ? v : 0.0f;
-            }
+            load8(q, zv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const __bf16 hh = (__bf16)zv[i];
@@ -159,16 +182,7 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
             for (int ks0 = kc0; ks0 < kc0 + kcn; ks0 += KSC) {
                 float zv[KSC][8];
 #pragma unroll
-                for (int q = 0; q < KSC; ++q)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int m = 16 * (ks0 + q) + 8 * h + i;
-                        const bool live = ok && m < g.M;
-                        const size_t idx = poff + (size_t)(live ? m : 0) * slab;
-                        float v = z[idx];
-                        if (gate && gate[idx] == 0.0f) v = 0.0f;
-                        zv[q][i] = live ? v : 0.0f;
-                    }
+                for (int q = 0; q < KSC; ++q) load8(ks0 + q, zv[q]);
 #pragma unroll
                 for (int q = 0; q < KSC; ++q) {
                     const int ks = ks0 + q;
@@ -291,6 +305,7 @@ bool plan_for(const cdl_geom *g, Plan *p)
     }
     if (p->lds > 150 * 1024) return false;
     if (p->tiles >= ((size_t)1 << 31) || g->H > 65535 || (size_t)g->N * g->C * g->D > 65535) return false;
+    if ((size_t)g->M * Dz * Hz * Wz * 4 >= ((size_t)1 << 31)) return false;   // one sample's code block behind a 32-bit buffer descriptor
     if (p->patch_floats > ((size_t)1 << 28)) return false;                     // 1 GiB of patches: not worth it
     return true;
 }
