@@ -46,6 +46,15 @@ __global__ void k_ana_prep(const float *__restrict__ w, uint4 *__restrict__ frag
     frags[((size_t)(R * KS + ks) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
+constexpr int OOB = 0x7fff0000;       // a vector offset beyond any descriptor: loads return 0, stores are dropped
+// buffer descriptor over [base, base + bytes) with the base made provably wave-uniform (cdl_fused2d.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base, size_t bytes)
+{
+    const size_t a = reinterpret_cast<size_t>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+
 template <int PH, int PW, int SW, int MT, bool PROX>
 __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restrict__ x,
                                                const uint4 *__restrict__ frags, float alpha,
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
             // 32-bit offsets inside the sample's block.  A thread keeps its PIXEL (element e = tid + 512 jj is channel
             // 2 jj + (tid >> 8) of pixel tid & 255), so everything but the channel stride is computed once per tile.
             static_assert(ANT == 2 * ALX * ALY, "thread <-> (channel parity, pixel) mapping");
-            constexpr int NB = PROX ? 8 : 16;               // (the CSR maps need their registers: 16 in flight spills there)
+            constexpr int NB = 8;                            // (fallback for > 2 GB sample blocks and the CSR maps)
             const float *zin_n = zin ? zin + nbase : nullptr;
             const float *gate_n = (zin && gate) ? gate + nbase : nullptr;
             float *out_n = out + nbase;
@@ -191,6 +200,39 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
             const bool okp = oy < Hz && ox < Wz;
             const int m0 = 32 * (r0 + R) + chh;
             const int idx0 = m0 * (int)slab + oy * Wz + ox, step = 2 * (int)slab;
+            if (!PROX && (size_t)g.M * slab * 4 < ((size_t)1 << 31)) {
+                // buffer descriptors over the sample's code block: the thread's pixel and channel parity are its vector
+                // offset, the channel pair 2 jj travels in the scalar offset -- no address arithmetic per element, and
+                // out-of-range elements are dropped by the range check (only the vector offset is checked: channels
+                // beyond M are masked per thread in the last channel tile)
+                const size_t sb = (size_t)n * g.M * slab;
+                const __amdgpu_buffer_rsrc_t rs_in = uniform_rsrc(zin ? zin + sb : out + sb, (size_t)g.M * slab * 4);
+                const __amdgpu_buffer_rsrc_t rs_g = uniform_rsrc((zin && gate) ? gate + sb : out + sb, (size_t)g.M * slab * 4);
+                const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc(out + sb, (size_t)g.M * slab * 4);
+                const int voff = okp ? (int)(((size_t)chh * slab + (size_t)zd * Hz * Wz + (size_t)oy * Wz + ox) * 4) : OOB;
+                const int slab4 = (int)slab * 4;
+                const int soff0 = __builtin_amdgcn_readfirstlane(32 * (r0 + R) * slab4);
+                const bool tailR = 32 * (r0 + R) + 32 > g.M;            // uniform
+                constexpr int NE = 32 * ALX * ALY / ANT;                // 16 elements per thread
+                // (keep this variant under 128 VGPRs: two workgroups per CU)
+                float bv[NE], gv[NE];
+#pragma unroll
+                for (int jj = 0; jj < NE; ++jj) {
+                    const int vo = (tailR && m0 + 2 * jj >= g.M) ? OOB : voff;
+                    bv[jj] = zin ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, soff0 + 2 * jj * slab4, 0)) : 0.0f;
+                    gv[jj] = (zin && gate) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo, soff0 + 2 * jj * slab4, 0)) : 1.0f;
+                }
+#pragma unroll
+                for (int jj = 0; jj < NE; ++jj) {
+                    const float base = gv[jj] == 0.0f ? 0.0f : bv[jj];
+                    const float u = fmaf(alpha, stage[threadIdx.x + jj * ANT], base);
+                    const float ts = tau_s[32 * R + chh + 2 * jj];          // (unused when tau == nullptr)
+                    const float val = tau ? (tau_neg ? cdl_shrink(u, ts) : u - __builtin_amdgcn_fmed3f(u, -ts, ts)) : u;
+                    const int vo = (tailR && m0 + 2 * jj >= g.M) ? OOB : voff;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, vo, soff0 + 2 * jj * slab4, 0);
+                }
+                continue;
+            }
 #pragma unroll 1
             for (int j0 = 0; j0 < 32 * ALX * ALY / ANT; j0 += NB) {
                 float bv[NB], gv[NB];
