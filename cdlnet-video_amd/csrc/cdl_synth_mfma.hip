@@ -278,6 +278,71 @@ __global__ __launch_bounds__(256) void k_synth_assemble(cdl_geom g, const float 
     out[i] = v;
 }
 
+// W % 4 == 0: 4 consecutive pixels x one row per thread, 16-byte thin accesses; a pixel lies in at most 2 x 2 patches per
+// depth tap (the patch halo P - 1 is smaller than a tile): the row candidates are wave-uniform, the column candidates
+// are read side by side, and the terms are added in k_synth_assemble's order (depth tap, tile row, tile column).
+template <int PH, int PW, int SW>
+__global__ __launch_bounds__(256) void k_synth_assemble4(cdl_geom g, const float *__restrict__ patches,
+                                                         const float *__restrict__ mask,
+                                                         const float *__restrict__ sub, float alpha,
+                                                         float *__restrict__ out, int tilesX, int tilesY)
+{
+    constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
+    constexpr int TWX = TCX * SW, TWY = TCY * SW;             // image pixels covered by a tile
+    static_assert(PX - TWX < TWX, "at most two tile columns per pixel (the tile-row loop is general)");
+    const int X0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X0 >= g.W || Y >= g.H) return;
+    int r = blockIdx.z;
+    const int d = r % g.D; r /= g.D;
+    const int c = r % g.C, n = r / g.C;
+    const int Dz = g.D / g.sd, G = g.C * g.Pd;
+    const int ay = Y + g.ph;
+    const int ty_hi = min(tilesY - 1, ay / TWY), ty_lo = max(0, (ay - PY + TWY) / TWY);
+    int offh[4], offl[4];
+    bool has_lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ax = X0 + e + g.pw;
+        const int tx_hi = min(tilesX - 1, ax / TWX), tx_lo = max(0, (ax - PX + TWX) / TWX);
+        has_lo[e] = tx_lo < tx_hi;
+        offh[e] = tx_hi * (G * PY * PX) + (ax - tx_hi * TWX);
+        offl[e] = tx_lo * (G * PY * PX) + (ax - tx_lo * TWX);
+    }
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kd = 0; kd < g.Pd; ++kd) {
+        const int td = d + g.pd - kd;
+        if (td < 0 || td % g.sd) continue;                    // uniform
+        const int zd = td / g.sd;
+        if (zd >= Dz) continue;
+        const int grp = c * g.Pd + kd;
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {             // uniform, 1 or 2 rows of tiles
+            const float *row = patches + (((((size_t)n * Dz + zd) * tilesY + ty) * tilesX * G + grp) * PY + (ay - ty * TWY)) * PX;
+            float lo[4], hi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = row[offh[e]];
+                lo[e] = has_lo[e] ? row[offl[e]] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (has_lo[e]) acc[e] += lo[e];
+                acc[e] += hi[e];
+            }
+        }
+    }
+    const size_t i = ((((size_t)n * g.C + c) * g.D + d) * g.H + Y) * g.W + X0;
+    float4 v = make_float4(alpha * acc[0], alpha * acc[1], alpha * acc[2], alpha * acc[3]);
+    if (mask) {
+        const float4 m = *reinterpret_cast<const float4 *>(mask + i);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+    if (sub) {
+        const float4 sv = *reinterpret_cast<const float4 *>(sub + i);
+        v.x -= sv.x; v.y -= sv.y; v.z -= sv.z; v.w -= sv.w;
+    }
+    *reinterpret_cast<float4 *>(out + i) = v;
+}
+
 struct Plan {
     int tilesX, tilesY, RT, KS, KCH;
     size_t tiles, frag_uint4, patch_floats, lds;
@@ -328,6 +393,13 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
     else
         k_synth_m<PH, PW, SW, 0><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
     CDL_LAUNCH_CHECK();
+    const size_t al = reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(mask) | reinterpret_cast<size_t>(sub);
+    if ((g->W & 3) == 0 && (al & 15) == 0 && !(cdl_opts().fused_debug & 512)) {     // (bit 512: the scalar form, for tests)
+        dim3 grid4((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
+        k_synth_assemble4<PH, PW, SW><<<grid4, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
+        CDL_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)(g->N * g->C * g->D));
     k_synth_assemble<PH, PW, SW><<<grid, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
     CDL_LAUNCH_CHECK();
