@@ -50,6 +50,7 @@ SIGNATURES = {
     "cdl_tau_grad": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_tau_grad_gate": [_G, _P, _P, _P, _P, _P, _P, _P],
     "cdl_analysis_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
+    "cdl_analysis_rev_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_analysis_prox_ws": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cdl_analysis_prox": [_G, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cdl_ista_forward": [_G, _I] + [_P] * 14 + [ctypes.c_size_t, _P],
@@ -92,7 +93,7 @@ SIZE_T_FUNCS = {"cdl_fusedg_frag_bytes": [_G], "cdl_fusedg_patch_floats": [_G], 
                 "cdl_fusedg_map_words": [_G], "cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G], "cdl_fused2d_code_bytes": [_G, _I],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],
-                "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G], "cdl_analysis_workspace_floats": [_G],
+                "cdl_synthesis_workspace_floats": [_G], "cdl_ista_scratch_floats": [_G], "cdl_analysis_workspace_floats": [_G], "cdl_analysis_rev_workspace_floats": [_G],
                 "cdl_nle_mad_scratch_floats": [_I, _I, _I, _I], "cdl_residual_scratch_floats": [_G]}
 
 _lib = None

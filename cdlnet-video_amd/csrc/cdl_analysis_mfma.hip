@@ -60,7 +60,8 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                                                const uint4 *__restrict__ frags, float alpha,
                                                const float *__restrict__ zin, const float *__restrict__ gate,
                                                const float *__restrict__ tau, float *__restrict__ out,
-                                               cdl_prox_args px, int tilesX, int tilesY, int KS)
+                                               cdl_prox_args px, int tilesX, int tilesY, int KS,
+                                               const float *__restrict__ zsup, float *__restrict__ dtp)
 {
     constexpr int XH = (ALY - 1) * SW + PH, XW = (ALX - 1) * SW + PW;
     constexpr int PS = ((XH * XW + 7) / 8) * 8;            // elements per plane
@@ -209,6 +210,10 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                 const __amdgpu_buffer_rsrc_t rs_in = uniform_rsrc(zin ? zin + sb : out + sb, (size_t)g.M * slab * 4);
                 const __amdgpu_buffer_rsrc_t rs_g = uniform_rsrc((zin && gate) ? gate + sb : out + sb, (size_t)g.M * slab * 4);
                 const __amdgpu_buffer_rsrc_t rs_out = uniform_rsrc(out + sb, (size_t)g.M * slab * 4);
+                // reverse mode (zsup): out = [zsup != 0] (zin + alpha A x), and the threshold-gradient partial of this
+                // tile, sum over its pixels of -sign(zsup) * out, per channel -- what cdl_tau_grad_gate computes from
+                // the tensor this launch writes (three fat passes of the generic reverse sweep)
+                const __amdgpu_buffer_rsrc_t rs_sup = uniform_rsrc(zsup ? zsup + sb : out + sb, (size_t)g.M * slab * 4);
                 const int voff = okp ? (int)(((size_t)chh * slab + (size_t)zd * Hz * Wz + (size_t)oy * Wz + ox) * 4) : OOB;
                 const int slab4 = (int)slab * 4;
                 const int soff0 = __builtin_amdgcn_readfirstlane(32 * (r0 + R) * slab4);
@@ -220,7 +225,42 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                 for (int jj = 0; jj < NE; ++jj) {
                     const int vo = (tailR && m0 + 2 * jj >= g.M) ? OOB : voff;
                     bv[jj] = zin ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, soff0 + 2 * jj * slab4, 0)) : 0.0f;
-                    gv[jj] = (zin && gate) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo, soff0 + 2 * jj * slab4, 0)) : 1.0f;
+                    // (the slot of the input gate carries the support tensor in reverse mode: the two never coincide)
+                    gv[jj] = zsup ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sup, vo, soff0 + 2 * jj * slab4, 0))
+                           : ((zin && gate) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo, soff0 + 2 * jj * slab4, 0)) : 1.0f);
+                }
+                if (zsup) {
+                    float tg[NE];
+#pragma unroll
+                    for (int jj = 0; jj < NE; ++jj) {
+                        const float sv = gv[jj];
+                        const float u = fmaf(alpha, stage[threadIdx.x + jj * ANT], bv[jj]);
+                        const float val = sv != 0.0f ? u : 0.0f;
+                        tg[jj] = sv > 0.0f ? -val : (sv < 0.0f ? val : 0.0f);
+                        const int vo = (tailR && m0 + 2 * jj >= g.M) ? OOB : voff;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, vo, soff0 + 2 * jj * slab4, 0);
+                    }
+                    // per-channel sums over the tile's 256 pixels through the staging buffer (every thread has read its
+                    // values): [32 channels][256 pixels], 16 threads per channel add 16 pixels each, then a fixed 4-step
+                    // exchange inside their 16-lane group -- order-fixed, deterministic
+                    __syncthreads();
+#pragma unroll
+                    for (int jj = 0; jj < NE; ++jj) stage[(2 * jj + chh) * (ALX * ALY) + pxl] = tg[jj];
+                    __syncthreads();
+                    const int ch = threadIdx.x >> 4, part = threadIdx.x & 15;
+                    float a = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a += stage[ch * (ALX * ALY) + part * 16 + i];
+                    a += __shfl_xor(a, 8, 16);
+                    a += __shfl_xor(a, 4, 16);
+                    a += __shfl_xor(a, 2, 16);
+                    a += __shfl_xor(a, 1, 16);
+                    const int mm = 32 * (r0 + R) + ch;
+                    if (part == 0 && mm < g.M) {
+                        const int S = Dz * tilesY * tilesX, kt = (zd * tilesY + ty) * tilesX + tx;
+                        dtp[((size_t)n * g.M + mm) * S + kt] = a;
+                    }
+                    continue;
                 }
 #pragma unroll
                 for (int jj = 0; jj < NE; ++jj) {
@@ -295,37 +335,104 @@ bool plan_for(const cdl_geom *g, Plan *p)
 
 template <int PH, int PW, int SW, int MT, bool PROX>
 int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
-               const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
+               const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st,
+               const float *zsup, float *dtp)
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX>, 96 * 1024)) return rc;
     k_ana_m<PH, PW, SW, MT, PROX><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
-        *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS);
+        *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS, zsup, dtp);
     CDL_LAUNCH_CHECK();
     return 0;
 }
 
 template <int PH, int PW, int SW, int MT>
 int launch_mt(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
-              const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st)
+              const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st,
+              const float *zsup, float *dtp)
 {
-    if (px.zp) return launch_mtp<PH, PW, SW, MT, true>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
-    return launch_mtp<PH, PW, SW, MT, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+    if (px.zp) return launch_mtp<PH, PW, SW, MT, true>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, nullptr, nullptr);
+    return launch_mtp<PH, PW, SW, MT, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, zsup, dtp);
 }
 
 template <int PH, int PW, int SW>
 int launch(const cdl_geom *g, const Plan &p, const float *x, const float *w, float alpha, const float *zin,
-           const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws, hipStream_t st)
+           const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws, hipStream_t st,
+           const float *zsup = nullptr, float *dtp = nullptr)
 {
     uint4 *frags = reinterpret_cast<uint4 *>(ws);
     const int ntile = p.ngy * p.MTW;
     const int nprep = ntile * p.KS * 64;
     k_ana_prep<<<(nprep + 255) / 256, 256, 0, st>>>(w, frags, g->M, g->C * g->Pd * g->Ph * g->Pw, ntile, p.KS);
     CDL_LAUNCH_CHECK();
-    if (p.MTW == 1) return launch_mt<PH, PW, SW, 1>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
-    return launch_mt<PH, PW, SW, 2>(g, p, x, frags, alpha, zin, gate, tau, out, px, st);
+    if (p.MTW == 1) return launch_mt<PH, PW, SW, 1>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, zsup, dtp);
+    return launch_mt<PH, PW, SW, 2>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, zsup, dtp);
+}
+
+// dt0[m] = sum_n sum_k s[(n M + m) S + k], dt1[m] = sum_n c[n] (...): one wave per channel; the lanes split the S tile
+// partials of a sample, a fixed exchange tree adds them, the 8 waves walk every 8th sample and are added in order --
+// deterministic.  (One thread
+// per channel walking N x S strided values took 0.40 ms at the s2030 shape: as long as the analysis itself.)
+__global__ __launch_bounds__(512) void k_ana_tau_final(const float *__restrict__ s, const float *__restrict__ c,
+                                                       float *__restrict__ dt0, float *__restrict__ dt1, int N, int M, int S)
+{
+    __shared__ float r0[8], r1[8];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int n = wv; n < N; n += 8) {                      // wave wv takes samples wv, wv + 8, ...
+        const float *row = s + (size_t)(n * M + m) * S;
+        float v = 0.0f;
+        for (int k = lane; k < S; k += 64) v += row[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        a0 += v;
+        if (c) a1 = fmaf(c[n], v, a1);
+    }
+    if (lane == 0) { r0[wv] = a0; r1[wv] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { t0 += r0[w]; t1 += r1[w]; }
+        dt0[m] = t0;
+        dt1[m] = t1;
+    }
 }
 
 }  // namespace
+
+// Reverse-sweep form: out = [zsup != 0] (zin + alpha A x) and (dt0, dt1) = cdl_tau_grad(out, zsup, c), one fat launch.
+// Workspace: cdl_mfma_analysis_rev_ws_floats(g) (fragments + N M S tile partials).  CDL_EUNSUPPORTED: the caller composes
+// cdl_analysis_ws and cdl_tau_grad_gate.
+size_t cdl_mfma_analysis_rev_ws_floats(const cdl_geom *g)
+{
+    Plan p;
+    if (!plan_for(g, &p)) return 0;
+    const size_t Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
+    if ((size_t)g->M * Dz * Hz * Wz * 4 >= ((size_t)1 << 31)) return 0;     // the descriptor epilogue only
+    return p.frag_uint4 * 4 + (size_t)g->N * g->M * Dz * p.tilesY * p.tilesX;
+}
+
+int cdl_mfma_analysis_rev(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                          const float *zsup, const float *c, float *dt0, float *dt1, float *out, float *ws,
+                          size_t ws_floats, void *stream)
+{
+    Plan p;
+    const size_t need = cdl_mfma_analysis_rev_ws_floats(g);
+    if (!need || !plan_for(g, &p) || !ws || ws_floats < need || !zsup || !dt0 || !dt1) return CDL_EUNSUPPORTED;
+    if ((reinterpret_cast<size_t>(ws) & 15) != 0) return CDL_EUNSUPPORTED;
+    float *dtp = ws + p.frag_uint4 * 4;
+    const int S_ = (g->D / g->sd) * p.tilesY * p.tilesX;
+    int rc = CDL_EUNSUPPORTED;
+#define CDL_M(P_, S2_) \
+    if (g->Pw == P_ && g->sw == S2_) rc = launch<P_, P_, S2_>(g, p, x, w, alpha, zin, nullptr, nullptr, out, cdl_prox_args{}, ws, S(stream), zsup, dtp)
+    CDL_M(3, 1); else CDL_M(5, 1); else CDL_M(7, 1); else CDL_M(9, 1);
+    else CDL_M(3, 2); else CDL_M(5, 2); else CDL_M(7, 2); else CDL_M(9, 2);
+#undef CDL_M
+    if (rc) return rc;
+    k_ana_tau_final<<<g->M, 512, 0, S(stream)>>>(dtp, c, dt0, dt1, g->N, g->M, S_);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
 
 size_t cdl_mfma_analysis_ws_floats(const cdl_geom *g)
 {

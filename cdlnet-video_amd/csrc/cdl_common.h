@@ -141,6 +141,10 @@ int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float a
                       const float *gate, const float *tau, float *out, const cdl_prox_args &px, float *ws,
                       size_t ws_floats, void *stream);
 size_t cdl_mfma_analysis_ws_floats(const cdl_geom *g);
+size_t cdl_mfma_analysis_rev_ws_floats(const cdl_geom *g);
+int cdl_mfma_analysis_rev(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                          const float *zsup, const float *c, float *dt0, float *dt1, float *out, float *ws,
+                          size_t ws_floats, void *stream);
 // matrix-core filter gradients (cdl_wgrad_mfma.hip), same convention
 int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
                    float *ws, size_t ws_floats, void *stream);

@@ -668,6 +668,36 @@ int cdl_analysis_ws(const cdl_geom *g, const float *x, const float *w, float alp
     return analysis_impl(g, x, w, alpha, zin, gate, tau, out, cdl_prox_args{}, workspace, workspace_floats, stream);
 }
 
+/* Reverse-sweep step: out = [zsup != 0] (zin + alpha A x)  and  (dt0, dt1) = cdl_tau_grad(out, zsup, c) -- the gradient
+ * with respect to z_k, gated by z_k's support, together with the threshold gradients it yields.  One launch where the
+ * matrix-core analysis covers the geometry (the gate and the per-tile threshold partials ride in its epilogue);
+ * otherwise cdl_analysis_ws followed by cdl_tau_grad_gate.  workspace: cdl_analysis_rev_workspace_floats(g). */
+size_t cdl_analysis_rev_workspace_floats(const cdl_geom *g)
+{
+    if (!cdl_geom_ok(g)) return 0;
+    size_t n = (size_t)CDL_TAU_SPLITS * g->N * g->M;
+    const size_t a = cdl_analysis_workspace_floats(g);
+    if (a > n) n = a;
+    const size_t r = (!cdl_opts().no_tiled && mfma_analysis_enabled(g)) ? cdl_mfma_analysis_rev_ws_floats(g) : 0;
+    return r > n ? r : n;
+}
+
+int cdl_analysis_rev_ws(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
+                        const float *zsup, const float *c, float *dt0, float *dt1, float *out, float *workspace,
+                        size_t workspace_floats, void *stream)
+{
+    if (!cdl_geom_ok(g) || !x || !w || !out || !zsup || !dt0 || !dt1 || !workspace) return CDL_EINVAL;
+    if (out == zin || out == zsup) return CDL_EINVAL;
+    if (workspace_floats < cdl_analysis_rev_workspace_floats(g)) return CDL_EINVAL;
+    if (!cdl_opts().no_tiled && mfma_analysis_enabled(g) && !(mfma_dense_enabled() && cdl_dense_ws_floats(g, 0) > 0)) {
+        const int rc = cdl_mfma_analysis_rev(g, x, w, alpha, zin, zsup, c, dt0, dt1, out, workspace, workspace_floats, stream);
+        if (rc != CDL_EUNSUPPORTED) return rc;
+    }
+    const int rc = cdl_analysis_ws(g, x, w, alpha, zin, nullptr, nullptr, out, workspace, workspace_floats, stream);
+    if (rc) return rc;
+    return cdl_tau_grad_gate(g, out, zsup, c, dt0, dt1, workspace, stream);
+}
+
 int cdl_analysis_prox(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin,
                       const float *z_prev, const float *z_after, const float *lam, const float *gam1,
                       const float *gam2, float *u_out, float *out, void *stream)

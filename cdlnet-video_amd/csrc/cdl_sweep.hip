@@ -24,6 +24,7 @@ size_t cdl_ista_scratch_floats(const cdl_geom *g)
     n = max_sz(n, cdl_synthesis_workspace_floats(g));
     n = max_sz(n, cdl_prox_csr_scratch_floats(g));
     n = max_sz(n, cdl_analysis_workspace_floats(g));
+    n = max_sz(n, cdl_analysis_rev_workspace_floats(g));
     return n;
 }
 
@@ -73,8 +74,17 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
     const size_t code = NM * (size_t)(g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
     const size_t flen = (size_t)g->M * g->C * g->Pd * g->Ph * g->Pw;
     float *gk = gbuf0, *other = gbuf1;
+    // Plain loop (no neighbour codes): the analysis that produces dL/dz_k also gates it by the support of z_k and
+    // reduces the threshold gradients of iteration k (cdl_analysis_rev_ws) -- the separate gate / threshold pass re-read
+    // and re-wrote the tensor the analysis had just written (3 of the reverse sweep's fat passes per iteration).
+    bool gated = false;                                        // gk already gated, dt_k already written
     if (g_xp) {
         CDL_TRY(cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], scratch, scratch_floats, stream));
+        if (!z_prev) {
+            CDL_TRY(cdl_analysis_rev_ws(g, g_xp, wB[0], 1.0f, g_z, z[K - 1], c, dt + (size_t)(K - 1) * 2 * M,
+                                        dt + (size_t)(K - 1) * 2 * M + M, gk, scratch, scratch_floats, stream));
+            gated = true;
+        } else
         CDL_TRY(cdl_analysis_ws(g, g_xp, wB[0], 1.0f, g_z, nullptr, nullptr, gk, scratch, scratch_floats, stream));   // B_0^T g_xp (+ g_z)
     } else {
         hipError_t e = hipMemsetAsync(dB[0], 0, flen * sizeof(float), S(stream));
@@ -89,7 +99,7 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
                                      gam2 ? gam2 + k * NM : nullptr, c, gk, gz_prev, gz_after, dt + k * 2 * M,
                                      dg1 + k * 2 * M, dg2 ? dg2 + k * 2 * M : nullptr, scratch, scratch_floats,
                                      stream));
-        } else {
+        } else if (!gated) {
             // threshold gradients, and gk gated in place by the support of z_{k+1} in the same pass: the synthesis,
             // the filter gradient and the analysis below then read no gate (3 fat reads less per iteration)
             CDL_TRY(cdl_tau_grad_gate(g, gk, z[k], c, dt + k * 2 * M, dt + k * 2 * M + M, scratch, stream));
@@ -100,6 +110,11 @@ int cdl_ista_backward(const cdl_geom *g, int K, const float *yp, const float *ma
         }
         CDL_TRY(cdl_synthesis_ws(g, gk, gate, wA[k], -1.0f, mask, nullptr, q, scratch, scratch_floats, stream));
         CDL_TRY(cdl_wgrad_pair(g, gk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], scratch, scratch_floats, stream));   // gk is gated in place above
+        if (!z_prev) {                                       // dL/dz_{k-1}, gated, with the thresholds' gradient of iteration k-1
+            CDL_TRY(cdl_analysis_rev_ws(g, q, wB[k], 1.0f, gk, z[k - 1], c, dt + (size_t)(k - 1) * 2 * M,
+                                        dt + (size_t)(k - 1) * 2 * M + M, other, scratch, scratch_floats, stream));
+            gated = true;
+        } else
         CDL_TRY(cdl_analysis_ws(g, q, wB[k], 1.0f, gk, gate, nullptr, other, scratch, scratch_floats, stream));
         float *t = gk;
         gk = other;

@@ -308,6 +308,25 @@ def tau_grad(g: Geometry, gup, zout, c, dt_k):
     _lib.check(rc, "cdl_tau_grad")
 
 
+def analysis_rev(g: Geometry, x, w, alpha, zin, zsup, c, dt_k, out=None):
+    """One reverse-sweep step (cdl_analysis_rev_ws): out = [zsup != 0] (zin + alpha A x), and the (2, M) threshold
+    gradient slice `dt_k` of `out` with respect to the code `zsup` -- cdl_analysis followed by cdl_tau_grad_gate, as one
+    fat launch where the matrix-core analysis covers the geometry."""
+    x, w, zin, zsup, c = _dev(x, "x"), _dev(w, "w"), _opt(zin, "zin"), _dev(zsup, "zsup"), _opt(c, "c")
+    if out is None:
+        out = _new(g.code_shape(), x.device)
+    assert dt_k.is_contiguous() and dt_k.numel() == 2 * g.M
+    gs = g.c_struct()
+    n = int(_lib.lib().cdl_analysis_rev_workspace_floats(ctypes.byref(gs)))
+    ws = _scratch(x.device, n)
+    base = dt_k.data_ptr()
+    rc = _lib.lib().cdl_analysis_rev_ws(ctypes.byref(gs), _ptr(x), _ptr(w), float(alpha), _ptr(zin), _ptr(zsup), _ptr(c),
+                                        ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * g.M), _ptr(out), _ptr(ws), n,
+                                        _stream())
+    _lib.check(rc, "cdl_analysis_rev_ws")
+    return out
+
+
 def prox_csr(g: Geometry, u, z_prev, lam, gam1, z_after=None, gam2=None, out=None):
     """prox_CSR (z_after None) / prox_CSR_f2 of net.py:229-262; lam, gam* are (N,M) like tau."""
     u, z_prev, lam, gam1 = _dev(u, "u"), _dev(z_prev, "z_prev"), _dev(lam, "lam"), _dev(gam1, "gam1")

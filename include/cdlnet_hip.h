@@ -99,6 +99,14 @@ int cdl_analysis_ws(const cdl_geom *g, const float *x, const float *w, float alp
                     const float *tau /*N*M, nullable*/, float *out, float *workspace, size_t workspace_floats,
                     void *stream);
 size_t cdl_analysis_workspace_floats(const cdl_geom *g);
+/* One step of the reverse sweep (autograd of net.py:87 / 205 through the shrinkage of the previous iteration):
+ *   out = [zsup != 0] * (zin + alpha * A x),   (dt0, dt1) = cdl_tau_grad(out, zsup, c)
+ * i.e. cdl_analysis_ws followed by cdl_tau_grad_gate, as ONE fat launch where the matrix-core analysis covers the
+ * geometry (gate and threshold partials in its epilogue).  out must differ from zin and zsup. */
+int cdl_analysis_rev_ws(const cdl_geom *g, const float *x, const float *w, float alpha, const float *zin /*nullable*/,
+                        const float *zsup, const float *c /*nullable*/, float *dt0, float *dt1, float *out,
+                        float *workspace, size_t workspace_floats, void *stream);
+size_t cdl_analysis_rev_workspace_floats(const cdl_geom *g);
 
 /* ---- synthesis half: F.conv_transpose2d/3d at net.py:87,90,205,210 and gabor.py:64 ----------
  *   v   = alpha * corrT( gate ? [gate!=0]*z : z ; w )   z fat, v thin, output_padding = s-1

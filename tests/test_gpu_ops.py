@@ -303,3 +303,32 @@ def test_synthesis_assemble_vector_form_is_bit_identical(hip_env):
             hip_env("CDL_FUSED_DEBUG", dbg)
             outs.append(o.synthesis(geom, z.cuda(), w.cuda(), -1.5, None, mask, x.cuda()))
         assert torch.equal(outs[0], outs[1]), (N, C, M, sp, P, s)
+
+
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+@pytest.mark.parametrize("N,C,M,sp,P,s", [SHAPES[1], SHAPES[3], SHAPES[5], SHAPES[10], SHAPES[11], SHAPES[12], SHAPES[14]])
+def test_reverse_analysis_step(N, C, M, sp, P, s, path, hip_env):
+    """cdl_analysis_rev_ws: out = [zsup != 0] (zin + alpha A x) with the threshold gradients of `out` -- fused into the
+    matrix-core analysis epilogue where that kernel exists, composed (analysis, then gate + threshold pass) elsewhere --
+    against the oracle."""
+    hip_env("CDL_MFMA_ANALYSIS", "1" if path == "mfma" else "0")
+    hip_env("CDL_MFMA_DENSE", "0")
+    o = ops()
+    x, z, w = make(N, C, M, sp, P, s, seed=4)
+    pad = tuple(p // 2 for p in P)
+    geom = o.Geometry.make(N, C, M, sp, P, pad, s)
+    gup = torch.randn(z.shape)
+    c = torch.rand(N)
+    want = (gup + 0.5 * O.analysis(x, w, s, pad)) * (z != 0)
+    dt = torch.zeros(2, M, device="cuda")
+    got = o.analysis_rev(geom, x.cuda(), w.cuda(), 0.5, gup.cuda(), z.cuda(), c.cuda(), dt)
+    tol = 2e-5 if path == "mfma" else 2e-6
+    tag = f"analysis_rev[{path}] N{N}C{C}M{M}{sp}P{P}s{s}"
+    check(tag + " out", got, want, tol)
+    assert bool((got[(z == 0).cuda()] == 0).all())
+    s_nm = -(torch.sign(z) * want).sum(dim=tuple(range(2, z.dim())))
+    check(tag + " dt0", dt[0], s_nm.sum(0), 2e-5)
+    check(tag + " dt1", dt[1], (c[:, None] * s_nm).sum(0), 2e-5)
+    dt2 = torch.zeros(2, M, device="cuda")
+    got2 = o.analysis_rev(geom, x.cuda(), w.cuda(), 0.5, gup.cuda(), z.cuda(), c.cuda(), dt2)
+    assert torch.equal(got, got2) and torch.equal(dt, dt2)              # deterministic
