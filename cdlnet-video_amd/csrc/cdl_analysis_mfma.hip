@@ -55,7 +55,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 
-template <int PH, int PW, int SW, int MT, bool PROX>
+template <int PH, int PW, int SW, int MT, bool PROX, bool REV>
 __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restrict__ x,
                                                const uint4 *__restrict__ frags, float alpha,
                                                const float *__restrict__ zin, const float *__restrict__ gate,
@@ -226,10 +226,10 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                     const int vo = (tailR && m0 + 2 * jj >= g.M) ? OOB : voff;
                     bv[jj] = zin ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, soff0 + 2 * jj * slab4, 0)) : 0.0f;
                     // (the slot of the input gate carries the support tensor in reverse mode: the two never coincide)
-                    gv[jj] = zsup ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sup, vo, soff0 + 2 * jj * slab4, 0))
+                    gv[jj] = REV ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sup, vo, soff0 + 2 * jj * slab4, 0))
                            : ((zin && gate) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo, soff0 + 2 * jj * slab4, 0)) : 1.0f);
                 }
-                if (zsup) {
+                if constexpr (REV) {
                     float tg[NE];
 #pragma unroll
                     for (int jj = 0; jj < NE; ++jj) {
@@ -333,13 +333,13 @@ bool plan_for(const cdl_geom *g, Plan *p)
     return true;
 }
 
-template <int PH, int PW, int SW, int MT, bool PROX>
+template <int PH, int PW, int SW, int MT, bool PROX, bool REV>
 int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *frags, float alpha, const float *zin,
                const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st,
                const float *zsup, float *dtp)
 {
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX>, 96 * 1024)) return rc;
-    k_ana_m<PH, PW, SW, MT, PROX><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX, REV>, 96 * 1024)) return rc;
+    k_ana_m<PH, PW, SW, MT, PROX, REV><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
         *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS, zsup, dtp);
     CDL_LAUNCH_CHECK();
     return 0;
@@ -350,8 +350,9 @@ int launch_mt(const cdl_geom *g, const Plan &p, const float *x, const uint4 *fra
               const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st,
               const float *zsup, float *dtp)
 {
-    if (px.zp) return launch_mtp<PH, PW, SW, MT, true>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, nullptr, nullptr);
-    return launch_mtp<PH, PW, SW, MT, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, zsup, dtp);
+    if (px.zp) return launch_mtp<PH, PW, SW, MT, true, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, nullptr, nullptr);
+    if (zsup) return launch_mtp<PH, PW, SW, MT, false, true>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, zsup, dtp);
+    return launch_mtp<PH, PW, SW, MT, false, false>(g, p, x, frags, alpha, zin, gate, tau, out, px, st, nullptr, nullptr);
 }
 
 template <int PH, int PW, int SW>
