@@ -71,6 +71,9 @@ for case in range(cases):
         r["wg"] = o.wgrad(g, z, x, 1.0)
         r["wg_gate"] = o.wgrad(g, u, x, -1.0, gate=z)
         r["pair0"], r["pair1"] = o.wgrad_pair(g, u * (z != 0), x, -1.0, z, x, 1.0)
+        dt = torch.zeros(2, M, device="cuda")
+        r["rev"] = o.analysis_rev(g, x, w, 0.7, u, z, tau[:, 0].contiguous(), dt)
+        r["rev_dt"] = dt
         res[mode] = r
     setenv("1")
     tag = f"N{N} C{C} M{M} {sp} P{P} s{s}"
