@@ -219,6 +219,35 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
         __syncthreads();
         // col2im into the patch of this (tile, group): fixed (ki, kj) order per output
         float *patch = patches + ((size_t)tile * G + grp) * (PY * PX);
+        if constexpr (SW == 2) {
+            // stride 2: output (Yl, Xl) collects tap (ki, kj) = (Yl % 2 + 2 j, Xl % 2 + 2 i) of code pixel (Yl / 2 - j,
+            // Xl / 2 - i), j, i < ceil(P / 2): a static 4 x 4 (P = 7) candidate grid -- reads at clamped addresses issued
+            // together, added in a fixed order under predicates -- instead of two data-dependent loops per output
+            constexpr int NJ = (PH + 1) / 2, NI = (PW + 1) / 2;
+            for (int o = threadIdx.x; o < PY * PX; o += SNT) {
+                const int Yl = o / PX, Xl = o % PX;
+                const int zy0 = Yl >> 1, zx0 = Xl >> 1, ky0 = Yl & 1, kx0 = Xl & 1;
+                float v[NJ][NI];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int zy = min(max(zy0 - j, 0), TCY - 1), zx = min(max(zx0 - i, 0), TCX - 1);
+                        const int ki = min(ky0 + 2 * j, PH - 1), kj = min(kx0 + 2 * i, PW - 1);
+                        v[j][i] = col[(ki * PW + kj) * (TCX * TCY) + zy * TCX + zx];
+                    }
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = NJ - 1; j >= 0; --j)                  // ascending code row, then ascending code column
+#pragma unroll
+                    for (int i = NI - 1; i >= 0; --i) {
+                        const bool ok = zy0 - j >= 0 && zy0 - j < TCY && ky0 + 2 * j < PH &&
+                                        zx0 - i >= 0 && zx0 - i < TCX && kx0 + 2 * i < PW;
+                        if (ok) sum += v[j][i];
+                    }
+                patch[o] = sum;
+            }
+        } else
         for (int o = threadIdx.x; o < PY * PX; o += SNT) {
             const int Yl = o / PX, Xl = o % PX;
             float sum = 0.0f;
