@@ -21,8 +21,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch                                    # noqa: E402
-import torch.distributed as dist                # noqa: E402
+# torch is imported by the ranks only (run_rank): the launcher below must start its children before anything in
+# this process can have initialised the GPU
+torch = dist = None
 
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
 T_START = time.perf_counter()
@@ -66,6 +67,42 @@ def parse():
                          "bit-identical to the reference layout), bf16 pixel-blocked (opt-in: half the fat bytes, "
                          "PSNR parity only), or fp32 in the reference's NCHW layout")
     return ap.parse_args()
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL), each
+    running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- what `python -m torch.distributed.run
+    --nproc-per-node N` would do.  The parent never imports torch or touches the GPU (nothing is exec'ed from a
+    process that has initialised it); rank 0's stdout (the one JSON line) is the parent's stdout, the other ranks'
+    stdout goes to stderr.  Any failing rank ends the job: the rest are terminated and the parent exits non-zero."""
+    import socket
+    import subprocess
+    assert "torch" not in sys.modules or not sys.modules["torch"].cuda.is_initialized()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's cross-process handles need it here
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    note(f"launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                note(f"launcher: rank {r} exited with {code}; stopping the others")
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def event_ms(fn, reps):
@@ -195,18 +232,32 @@ def cpu_baseline(sd, x, y, sigma, K, P, reps=2):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    run_rank(args)
+
+
+def run_rank(args):
+    global torch, dist
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # one rank per GPU over RCCL ("nccl" on ROCm).  CDL_DIST_BACKEND=gloo rehearses the multi-rank
     # code path on a box with fewer GPUs than ranks (ranks then share devices round-robin).
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     ndev = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("CDL_DIST_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {ndev} visible "
+                         f"(CDL_DIST_BACKEND=gloo rehearses the multi-rank path on fewer)")
     dev_index = (local % ndev) if world > 1 else 0
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CDL_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -229,6 +280,8 @@ def main():
     broadcast_parameters(net)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     bucket = GradientBucket(net.parameters())
+    if world > 1:
+        bucket.attach()          # the all-reduce is queued from the end of the reverse sweep (loop.on_backward_end)
 
     # synthetic data, generated once and resident in HBM before timing (seeded per rank)
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -239,7 +292,7 @@ def main():
 
     def step():
         loss, _ = cva.train_step(net, opt, x, 25, clip_grad=5e-2, project=True,
-                                 grad_sync=bucket.sync if world > 1 else None, generator=dgen)
+                                 generator=dgen)
         return loss
 
     def barrier():
@@ -259,7 +312,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed * 1e3 / args.steps
@@ -270,7 +323,7 @@ def main():
     # forward-only (inference) rate on the same batch, for BASELINE.md's fwd column
     with torch.no_grad():
         y_inf = x + torch.randn(x.shape, device=dev, generator=dgen) * 25 / 255
-        fwd_ms = event_ms(lambda: net(y_inf, 25.0), 2)
+        fwd_ms = sorted(event_ms(lambda: net(y_inf, 25.0), 1) for _ in range(5))[2]      # median of 5
     fwd_mpix = B * S * S / (fwd_ms * 1e-3) / 1e6
 
     out = None
@@ -317,6 +370,9 @@ def main():
             "config": {"workload": f"CDLNet K={K} M={M} P={P} s=1 C=1 train step (fwd+bwd+Adam+project), "
                                    f"batch {B}x1x{S}x{S} per GPU, sigma=25",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
+            "rccl_world": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "grad_syncs_per_step": (bucket.syncs / max(args.steps + args.warmup, 1)) if world > 1 else 0,
             "fwd_only_mpix_s": round(fwd_mpix, 3), "fwd_ms": round(fwd_ms, 3),
             "loss": float(loss),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(d["GBps"], 2),

@@ -50,6 +50,33 @@ def set_code_layout(name):
     CODE_LAYOUT = name
 
 
+# Callables to run once per backward pass, queued on the autograd engine from the end of a reverse sweep (they run
+# after the engine has accumulated every gradient of that pass): the data-parallel gradient exchange
+# (parallel.GradientBucket.attach).
+_BACKWARD_END = []
+_queued = [False]
+
+
+def on_backward_end(fn):
+    """Register `fn()` to run at the end of every backward pass that contains a reverse sweep of this module;
+    returns a callable that removes it."""
+    _BACKWARD_END.append(fn)
+    return lambda: _BACKWARD_END.remove(fn) if fn in _BACKWARD_END else None
+
+
+def _queue_backward_end():
+    if not _BACKWARD_END or _queued[0]:
+        return                                    # e.g. MC-SURE: two sweeps in one pass, one exchange
+    _queued[0] = True
+
+    def run():
+        _queued[0] = False
+        for fn in list(_BACKWARD_END):
+            fn()
+
+    torch.autograd.Variable._execution_engine.queue_callback(run)
+
+
 def _forward_generic(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
     """Whole sweep from one C call (cdl_ista_forward): same launches as the stepwise form below."""
     keep = keep_codes or keep_resid
@@ -189,6 +216,16 @@ def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z,
     return dA, dB
 
 
+def _no_data_gradients(ctx):
+    """The reverse sweeps produce parameter (and neighbour-code) gradients only.  The reference's loop is
+    differentiable in the observation, the mask and sigma as well (no caller in the reference uses that); asking for
+    those here must fail loudly rather than return a silent None."""
+    for idx, name in ((0, "y"), (1, "mask"), (2, "sigma")):
+        if ctx.needs_input_grad[idx]:
+            raise NotImplementedError(f"cdlnet_video_amd: the gradient with respect to `{name}` is not implemented "
+                                      f"(the HIP reverse sweep returns parameter gradients only); detach() it")
+
+
 class UnrolledISTA(torch.autograd.Function):
     """(y, mask, c, t, A_0..A_{K-1}, B_0..B_{K-1}) -> (xhat, z_K[, z_1..z_{K-1}])."""
 
@@ -206,6 +243,7 @@ class UnrolledISTA(torch.autograd.Function):
         tau = ops.thresholds(t, c, N)
 
         ctx.set_materialize_grads(False)          # an unused z output must not cost a fat zero tensor
+        _no_data_gradients(ctx)
         keep = any(ctx.needs_input_grad)          # all False under torch.no_grad()
         want_codes = cfg.get("all_codes", False)
         ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
@@ -259,6 +297,7 @@ class UnrolledISTA(torch.autograd.Function):
         else:
             dA, dB = _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
 
+        _queue_backward_end()
         return (None, None, None, dt.reshape(t.shape), None, *dA, *dB)
 
 
@@ -321,6 +360,7 @@ class TemporalISTA(torch.autograd.Function):
         lam, gam1 = ops.thresholds(t, c, N), ops.thresholds(g1, c, N)
         gam2 = ops.thresholds(g2, c, N) if za is not None else None
         ctx.set_materialize_grads(False)
+        _no_data_gradients(ctx)
         keep = any(ctx.needs_input_grad)
         xp, z, us, codes, resid = _forward_csr(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep)
         xhat = ops.postprocess(xp, mean, pads)
@@ -359,6 +399,7 @@ class TemporalISTA(torch.autograd.Function):
         else:
             dA, dB = ops.ista_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z,
                                        dt, list(us), zp, za, lam, gam1, gam2, dg1, dg2, gzp, gza)
+        _queue_backward_end()
         return (None, None, None, gzp, gza, dt.reshape(t.shape), dg1.reshape(g1.shape),
                 dg2.reshape(g2.shape) if dg2 is not None else None, None, *dA, *dB)
 
@@ -437,6 +478,7 @@ class _Dictionary(torch.autograd.Function):
         g_xp = ops.postprocess_bwd(g_xhat.contiguous(), ctx.pads)
         dB = ops.wgrad(ctx.g, z, g_xp, 1.0)
         gz = ops.analysis(ctx.g, g_xp, wB, 1.0, None, None, None)
+        _queue_backward_end()
         return gz, dB, None, None, None
 
 
@@ -445,6 +487,9 @@ def run_residual(y, mask, c, t, A, B, s, blocks, all_codes=False):
     Returns (xhat, z) or, with all_codes, (xhat, z, ST outputs of every iteration) as forward_generator
     yields them (net.py:218-224: the code BEFORE its block)."""
     K = len(A)
+    if torch.is_grad_enabled() and (y.requires_grad or (torch.is_tensor(mask) and mask.requires_grad)
+                                    or (c is not None and c.requires_grad)):
+        raise NotImplementedError("cdlnet_video_amd: gradients with respect to y / mask / sigma are not implemented")
     yp, mean, pads, mask_p = ops.preprocess(y, s, mask)
     N, C = yp.shape[:2]
     P = tuple(A[0].shape[2:])

@@ -42,6 +42,24 @@ class GradientBucket:
             self.offsets.append(off)
             off += p.numel()
         self.copies = 0                      # device copies issued by the last adopt() (tests / diagnostics)
+        self.syncs = 0                       # sync() calls so far
+        self._hook = None
+
+    def attach(self):
+        """Issue `sync()` from the END OF THE REVERSE SWEEP instead of from the training loop: the sweep's autograd
+        node queues it on the engine (loop.on_backward_end), so it runs as soon as the last gradient has been
+        accumulated -- the exchange is enqueued right behind the sweep's last kernel with no trainer code in
+        between.  (The bucket is 0.8-3.2 MB and latency-bound, SURVEY.md section 5: it travels as one call; slicing
+        it per iteration to overlap the sweep would multiply the latency term it is bound by.)"""
+        from . import loop
+        if self._hook is None:
+            self._hook = loop.on_backward_end(self.sync)
+        return self
+
+    def detach(self):
+        if self._hook is not None:
+            self._hook()
+            self._hook = None
 
     def adopt(self):
         """Make every .grad a view into the bucket (gradients that are not there yet are copied in, runs of
@@ -85,6 +103,7 @@ class GradientBucket:
     def sync(self):
         """Sum over ranks, divide by world size (mean-of-means == global-batch mean for equal shards)."""
         self.adopt()
+        self.syncs += 1
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             _all_reduce_sum(self.flat, self.group)
             self.flat.div_(dist.get_world_size(self.group))

@@ -28,7 +28,7 @@ def main():
     net = net.cuda()
     broadcast_parameters(net, src=0)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    bucket = GradientBucket(net.parameters())
+    bucket = GradientBucket(net.parameters()).attach()             # sync() is queued by the reverse sweep itself
     x_all = cva.utils.synthetic_clip((4, 1, 40, 72), seed=7)       # the GLOBAL batch, same on every rank
     noise = torch.randn(x_all.shape, generator=torch.Generator().manual_seed(8)) * 25 / 255
     x, nz = shard_batch(x_all, rank, world).cuda(), shard_batch(noise, rank, world).cuda()
@@ -38,8 +38,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         xhat, _ = net(x + nz, 25.0)
         loss = torch.mean((x - xhat) ** 2)
-        loss.backward()
-        bucket.sync()                                              # mean over ranks == global-batch gradient
+        loss.backward()                                            # ... + the exchange: mean over ranks
+        assert bucket.syncs == step + 1, bucket.syncs              # exactly one per backward pass, no trainer call
         copies.append(bucket.copies)
         if step == 0:
             first_grads = {n_: p.grad.detach().cpu().clone() for n_, p in net.named_parameters() if p.grad is not None}

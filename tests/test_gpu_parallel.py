@@ -54,6 +54,25 @@ def test_two_ranks_stay_identical_and_match_the_global_batch_gradient(tmp_path):
             check(f"DP world-2 averaged gradient vs global batch: {n_}", res["first_grads"][n_], p.grad, 2e-5)
 
 
+def test_bench_gpus_2_runs_two_ranks_and_reports_them():
+    """`python bench.py --gpus 2` (no external launcher) starts two fresh ranks; here they share
+    the one GPU over a gloo group (CDL_DIST_BACKEND=gloo), on a multi-GPU node the same command runs over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CDL_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--size", "128", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 8 and out["dist_backend"] == "gloo"
+    assert out["grad_syncs_per_step"] == 1.0             # the exchange ran once per step, queued by the reverse sweep
+    assert out["value"] > 0 and out["steps"] == 2
+
+
 def test_net_on_a_non_current_device():
     """a module moved to cuda:1 without torch.cuda.set_device(1) must run on cuda:1's stream with
     cuda:1's launch attributes (ops.py makes the tensors' device current per call; the library keeps its launch
