@@ -108,7 +108,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
         tau_s[threadIdx.x] = m < g.M ? tau[(size_t)n * g.M + m] : 0.0f;
     }
     __syncthreads();
-    const bool tau_neg = tau && __syncthreads_or(threadIdx.x < 32 * MT && tau_s[threadIdx.x] < 0.0f);
+    const bool tau_neg = tau && __syncthreads_or(threadIdx.x < 32 * MT && !(tau_s[threadIdx.x] >= 0.0f));   // negative OR NaN
     const size_t slab = (size_t)Dz * Hz * Wz;
     const int pixbase = (wv * SW) * XW + l32 * SW;
 

@@ -90,18 +90,34 @@ __host__ __device__ __forceinline__ int cdl_floordiv(int a, int b)
     return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
+// ---- timing-ablation switches: compiled OUT of the product library ------------------------------------------
+// The kernels carry run-time switches that turn parts of them off for timing experiments (results are then wrong).
+// They exist only in the probe build (`make libcdlnet_hip_ablate.so`, -DCDL_ABLATE, loaded by the tools through
+// CDLNET_HIP_LIB); in libcdlnet_hip.so CDL_DBG() is the constant 0, the kernels' parameter blocks have no debug
+// field, and CDL_FUSED_DEBUG / CDL_DENSE_DEBUG are not read.
+#ifdef CDL_ABLATE
+#define CDL_DBG(flags, bit) (((flags) & (bit)) != 0)
+#define CDL_DBG_FIELD(decl) decl
+#define CDL_DBG_COMMA(x) , x
+#else
+#define CDL_DBG(flags, bit) (false)
+#define CDL_DBG_FIELD(decl)
+#define CDL_DBG_COMMA(x)
+#endif
+
 // ---- process-wide switches and per-device bookkeeping (cdl_options.hip) ---------------------------------
 struct cdl_options {
     int mfma_analysis, mfma_synthesis, mfma_wgrad, mfma_dense;   // 0: use the fp32 VALU kernels instead (CDL_MFMA_*=0)
     int no_tiled, no_pipelined_synthesis;                        // CDL_NO_TILED, CDL_NO_PIPELINED_SYNTHESIS
     int fused_snake;                                             // CDL_FUSED_SNAKE=0: no alternating tile direction
     int fused_grid;                                              // CDL_FUSED_GRID=n: fewer persistent workgroups (probes)
-    int fused_debug, dense_debug;                                // timing-experiment bit masks (results are wrong)
+    int scalar_assemble;                                         // CDL_SCALAR_ASSEMBLE=1: the one-pixel-per-thread patch assemble (tests)
+    int fused_debug, dense_debug;                                // -DCDL_ABLATE builds only (always 0 in the product)
 };
 const cdl_options &cdl_opts();                                   // snapshot of the environment, read once
 int cdl_current_device();
 int cdl_cu_count();                                              // compute units of the CURRENT device
-int cdl_ensure_dynamic_lds(const void *kernel, int bytes);       // per (device, kernel): raise the dynamic-LDS limit once
+int cdl_ensure_dynamic_lds(const void *kernel, int bytes);       // per (device, kernel): keep the dynamic-LDS limit >= bytes
 
 static inline bool cdl_geom_ok(const cdl_geom *g)
 {

@@ -39,7 +39,7 @@ struct DenseArgs {
     int relu;
     float *out;
     int N, I, O, D, H, W, Pd, Ph, Pw, tilesX, tilesY, NCC, MTT;
-    int dbg;                                               // CDL_DENSE_DEBUG (timing probes only): 1 no global loads, 2 no MFMAs, 4 no epilogue
+    CDL_DBG_FIELD(int dbg;)                                // probe build only (CDL_DENSE_DEBUG): 1 no global loads, 2 no MFMAs, 4 no epilogue
 };
 
 // frags[(((cc*Pd + kd)*taps + tap)*MTT + R)*2 + {hi,lo}][64]: lane (l32, h) holds output channel o = 32R + l32,
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
                 const size_t base = ((size_t)n * a.I + c0) * slab + (size_t)d * plane + (size_t)yy * a.W + xx;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (c0 + e < a.I && !(a.dbg & 1)) v[e] = a.x[base + e * slab];
+                    if (c0 + e < a.I && !CDL_DBG(a.dbg, 1)) v[e] = a.x[base + e * slab];
                 if (a.in_gate) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
             u32x4 wreg[NWR];
 #pragma unroll
             for (int j = 0; j < NWR; ++j) {
-                const int i = (threadIdx.x + j * DNT < nW && !(a.dbg & 1)) ? threadIdx.x + j * DNT : 0;
+                const int i = (threadIdx.x + j * DNT < nW && !CDL_DBG(a.dbg, 1)) ? threadIdx.x + j * DNT : 0;
                 const int tap = i / (MT * 128), rem = i - tap * (MT * 128);
                 wreg[j] = fs[(unsigned)((tap * a.MTT + r0) * 128 + rem)];
             }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
         __syncthreads();
         int ki = 0, kj = 0;
 #pragma unroll 1
-        for (int tap = 0; tap < ((a.dbg & 2) ? 0 : taps); ++tap) {
+        for (int tap = 0; tap < (CDL_DBG(a.dbg, 2) ? 0 : taps); ++tap) {
             bf16x8 bh[2], bl[2];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(DNT, 4) void k_dense(DenseArgs a)   // HIP: 2nd arg
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = ty * DTY + 2 * wv + rr;
-        if (y >= a.H || x >= a.W || (a.dbg & 4)) continue;
+        if (y >= a.H || x >= a.W || CDL_DBG(a.dbg, 4)) continue;
         const int pix = y * a.W + x;
 #pragma unroll
         for (int R = 0; R < MT; ++R) {
@@ -261,12 +261,9 @@ bool dense_plan(const cdl_geom *g, int in, int out, DensePlan *p)
 template <int MT>
 int launch_dense(const DensePlan &p, const DenseArgs &a, hipStream_t st)
 {
-    static size_t attr = 0;
-    if (p.lds > 64 * 1024 && p.lds > attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_dense<MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr = 160 * 1024;
+    if (p.lds > 64 * 1024) {
+        const int rc = cdl_ensure_dynamic_lds((const void *)k_dense<MT>, 160 * 1024);      // per device
+        if (rc) return rc;
     }
     k_dense<MT><<<dim3((unsigned)p.tiles, (unsigned)p.ngy), DNT, p.lds, st>>>(a);
     CDL_LAUNCH_CHECK();
@@ -300,8 +297,8 @@ int cdl_dense_conv(const cdl_geom *g, int transpose, const float *x, const float
                                                               transpose);
     CDL_LAUNCH_CHECK();
     const DenseArgs a{x, in_gate, frags, alpha, add, add_gate, mask, sub, tau, out_gate, relu, out,
-                      g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT,
-                      cdl_opts().dense_debug};
+                      g->N, in, outc, g->D, g->H, g->W, g->Pd, g->Ph, g->Pw, p.tilesX, p.tilesY, p.NCC, p.MTT
+                      CDL_DBG_COMMA(cdl_opts().dense_debug)};
     return p.MT == 2 ? launch_dense<2>(p, a, S(stream)) : launch_dense<1>(p, a, S(stream));
 }
 
@@ -406,7 +403,7 @@ template <bool VEC>
 __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G, const float *__restrict__ gate,
                                                      const float *__restrict__ X, float *__restrict__ partial,
                                                      int N, int O, int I, int D, int H, int W, int Pd, int tilesX,
-                                                     int tilesY, int ntiles, int dbg)
+                                                     int tilesY, int ntiles CDL_DBG_COMMA(int dbg))
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *gh = reinterpret_cast<__bf16 *>(smem);         // [64][GST]
@@ -536,8 +533,8 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
     };
 
     int tile = next_tile(blockIdx.x);
-    if (tile < ntiles && !(dbg & 1)) load_tile(tile);
-    if (dbg & 1) {
+    if (tile < ntiles && !CDL_DBG(dbg, 1)) load_tile(tile);
+    if CDL_DBG(dbg, 1) {
 #pragma unroll
         for (int j = 0; j < NG; ++j)
 #pragma unroll
@@ -552,11 +549,11 @@ __global__ __launch_bounds__(WNT) void k_dense_wgrad(const float *__restrict__ G
 #pragma unroll 1
     while (tile < ntiles) {
         __syncthreads();                                   // the previous tile's readers are done
-        if (!(dbg & 4)) store_tile();
+        if (!CDL_DBG(dbg, 4)) store_tile();
         __syncthreads();
         tile = next_tile(tile + gridDim.x);
-        if (tile < ntiles && !(dbg & 1)) load_tile(tile);
-        if (!(dbg & 2)) {
+        if (tile < ntiles && !CDL_DBG(dbg, 1)) load_tile(tile);
+        if (!CDL_DBG(dbg, 2)) {
             if (narrow) {
                 switch (wv) {                              // wave-uniform
                 case 0: wgrad_tile<0, 1>(gh, gl, xh, xl, 0, 0, l32, h, acc); break;
@@ -654,14 +651,14 @@ int cdl_dense_wgrad(const cdl_geom *g, const float *F, const float *gate, const 
     const size_t lds = (size_t)(64 * GST + 64 * XST) * 2 * sizeof(__bf16);
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_dense_wgrad<true>, (int)lds)) return rc;
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_dense_wgrad<false>, (int)lds)) return rc;
-    const int dbg = cdl_opts().dense_debug;
+    CDL_DBG_FIELD(const int dbg = cdl_opts().dense_debug;)
     const dim3 grid((unsigned)p.nwg, (unsigned)g->Pd, (unsigned)p.ogroups);
     if (vec)
         k_dense_wgrad<true><<<grid, WNT, lds, S(stream)>>>(F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd,
-                                                           p.tilesX, p.tilesY, p.ntiles, dbg);
+                                                           p.tilesX, p.tilesY, p.ntiles CDL_DBG_COMMA(dbg));
     else
         k_dense_wgrad<false><<<grid, WNT, lds, S(stream)>>>(F, gate, x, ws, g->N, g->M, g->C, g->D, g->H, g->W, g->Pd,
-                                                            p.tilesX, p.tilesY, p.ntiles, dbg);
+                                                            p.tilesX, p.tilesY, p.ntiles CDL_DBG_COMMA(dbg));
     CDL_LAUNCH_CHECK();
     k_dense_wfold<<<(unsigned)(g->M * g->Pd * 9), 256, 0, S(stream)>>>(ws, dw, alpha, g->M, g->C, g->Pd, p.nwg);
     CDL_LAUNCH_CHECK();

@@ -74,7 +74,7 @@ struct FusedParams {
     float *patches;          // (N,tilesY,tilesX,RTH,RTW)
     float sgn;               // u = zin + sgn * acc
     int do_synth;            // 0: skip the synthesis-like half (last backward stage)
-    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis, 32 no LDS adds, 64 no ST,
+    CDL_DBG_FIELD(int dbg;)  // probe build only (CDL_FUSED_DEBUG): 1 no stores, 2 no synthesis, 32 no LDS adds, 64 no ST,
                              // 4 no analysis MFMAs, 8 no thin staging, 16 no fat loads; results are wrong
     int N, H, W, tilesX, tilesY;
     int rev;                 // walk the tiles from the last to the first (see "snake order" at the sweeps)
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             const int yy = i / RTW, xx = i % RTW;
             const int gy = tyi * TH - HALO + yy, gx = txi * TW - HALO + xx;
             float v = 0.0f;
-            if (i < RTH * RTW && t < numTiles && !(p.dbg & 8) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+            if (i < RTH * RTW && t < numTiles && !CDL_DBG(p.dbg, 8) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
                 v = rimg[(size_t)gy * p.W + gx];
             stg[k] = v;
         }
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     // thresholds are >= 0 whenever project() runs (net.py:70); a negative one (3-D trainer, never projected) sends
     // the whole tile through the general shrinkage -- wave-uniform, so the common case pays 3 instructions per
     // element (u - clamp(u, -t, t)) instead of 10
-    const bool tau_neg = MODE != MODE_BWD && __ballot(lane < M && tau_s[lane] < 0.0f) != 0ull;
+    const bool tau_neg = MODE != MODE_BWD && __ballot(lane < M && !(tau_s[lane] >= 0.0f)) != 0ull;   // negative OR NaN: the general, NaN-preserving form
     float taur[MT * 16];                     // forward: this lane's 16 MT thresholds
     if (MODE != MODE_BWD) {
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         const int voff = valid ? lane_off + y * p.W * 4 : OOB;
         const int blk = (y * XB + xb) * (M / 4) * 32;            // first [px][4 ch] slot of the block
         const int voff_in = LIN == LAY_NCHW ? voff : (valid ? blk * EB_IN + lane_blk_in : OOB);
-        const int voff_st = (p.dbg & 1) ? OOB : (LOUT == LAY_NCHW ? voff : (valid ? blk * EB_OUT + lane_blk_out : OOB));
+        const int voff_st = CDL_DBG(p.dbg, 1) ? OOB : (LOUT == LAY_NCHW ? voff : (valid ? blk * EB_OUT + lane_blk_out : OOB));
 
         // -- fat inputs of this block, issued first: the analysis MFMAs below (and the partner
         //    wave on this SIMD) run while they are in flight
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         u32x2 zr[MT][4];                     // LAY_BLK16: packed, decoded in the epilogue
         if (MODE != MODE_FIRST && LIN == LAY_BLK16) {
             blk16_load_raw<MT>(zr, rs_in, voff_in);
-        } else if (MODE != MODE_FIRST && (p.dbg & 16)) {
+        } else if (MODE != MODE_FIRST && CDL_DBG(p.dbg, 16)) {
 #pragma unroll
             for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         for (int R = 0; R < MT; ++R)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[R][v] = 0.0f;
-        if (p.dbg & 4) {
+        if CDL_DBG(p.dbg, 4) {
 #pragma unroll
             for (int R = 0; R < MT; ++R) acc[R][0] = (float)rh[0][0] + (float)rl[1][1];
         } else {
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     const float tt = taur[16 * R + v];
                     const float st = decltype(general_shrink)::value ? cdl_shrink(u, tt)
                                                                      : u - __builtin_amdgcn_fmed3f(u, -tt, tt);
-                    zz = (p.dbg & 64) ? u : (valid ? st : 0.0f);
+                    zz = CDL_DBG(p.dbg, 64) ? u : (valid ? st : 0.0f);
                 }
                 if (LOUT == LAY_BLK16) zz = bf16_round(zz);             // the code IS its stored value from here on
                 if (LOUT == LAY_NCHW) buf_st(zz, rs_out, voff_st, chl * hw4);
@@ -636,13 +636,13 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     ws |= (zz != 0.0f ? 1u : 0u) << (16 * R + v);
                     wg |= (__builtin_bit_cast(unsigned, zz) >> 31) << (16 * R + v);
                 }
-            if (valid && !(p.dbg & 1)) {
+            if (valid && !CDL_DBG(p.dbg, 1)) {
                 map_n[(size_t)y * p.W + x] = ws;
                 map_n[HW + (size_t)y * p.W + x] = wg;
             }
         }
         if (MODE == MODE_BWD && !p.do_synth) continue;
-        if (p.dbg & 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
+        if CDL_DBG(p.dbg, 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
         __builtin_amdgcn_sched_barrier(0);
         // -- synthesis-like GEMM: the accumulator tiles are the B operand (k = channel) as they stand
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         // so no atomics and no read-modify-write are needed and the result is order-independent.
         {
             const float cs = col2im_row(ring[0], h);
-            if (lane < 38 && !(p.dbg & 32)) rsum[yl * RTW + 32 * wxi + lane] = cs;
+            if (lane < 38 && !CDL_DBG(p.dbg, 32)) rsum[yl * RTW + 32 * wxi + lane] = cs;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const float cs = col2im_row(ring[i], h);
-            if (lane < 38 && !(p.dbg & 32)) rsum[(wyi * RB + RB + i) * RTW + 32 * wxi + lane] = cs;
+            if (lane < 38 && !CDL_DBG(p.dbg, 32)) rsum[(wyi * RB + RB + i) * RTW + 32 * wxi + lane] = cs;
         }
     }
     if (MODE == MODE_BWD) {
@@ -1338,7 +1338,7 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     p.rev = f.rev;
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
     p.frags = reinterpret_cast<const uint4 *>(frags);
-    p.patches = patches; p.sgn = sgn; p.do_synth = 1; p.dbg = debug_flags();
+    p.patches = patches; p.sgn = sgn; p.do_synth = 1; CDL_DBG_FIELD(p.dbg = debug_flags();)
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, f, S(stream));
@@ -1357,7 +1357,7 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     p.rev = f.rev;
     p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
-    p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; p.dbg = debug_flags();
+    p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; CDL_DBG_FIELD(p.dbg = debug_flags();)
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
     return dispatch_stage(g, p, MODE_BWD, f, S(stream));
@@ -1412,7 +1412,7 @@ int cdl_fused2d_assemble(const cdl_geom *g, const float *patches, const float *m
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
-    if ((size_t)g->N * g->H * g->W >= ((size_t)1 << 20) && (g->W & 3) == 0 && !(cdl_opts().fused_debug & 512)) {
+    if ((size_t)g->N * g->H * g->W >= ((size_t)1 << 20) && (g->W & 3) == 0 && !cdl_opts().scalar_assemble) {
         dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 7) / 8), (unsigned)g->N);
         k_assemble_v4<<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, tiles_x(g), tiles_y(g));
     } else if ((size_t)g->N * g->H * g->W >= ((size_t)1 << 20)) {

@@ -71,7 +71,7 @@ struct GParams {
     int do_synth;
     int N, C, M, D, H, W, Pd, tilesX, tilesY, KS, rev;
     unsigned long long *tl;  // profiling hook (cdl_fusedg_set_timeline): s_memtime stamps of workgroup 0, [wave][256]
-    int dbg;                 // timing experiments only (CDL_FUSED_DEBUG; results are wrong): 1 no thin staging after the
+    CDL_DBG_FIELD(int dbg;)  // probe build only (CDL_FUSED_DEBUG; results are wrong): 1 no thin staging after the
                              // first tile, 2 no analysis GEMM, 4 no synthesis / col2im, 8 no fat loads, 16 no fat stores,
                              // 32 no patch combine
 };
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
     bool stg_ok[NSTG];
     unsigned stg_planes = 0;
     auto stage_load = [&](int t) {
-        const bool skip = t >= numTiles || ((p.dbg & 1) && t != (int)blockIdx.x);
+        const bool skip = t >= numTiles || (CDL_DBG(p.dbg, 1) && t != (int)blockIdx.x);
         int bid = p.rev ? numTiles - 1 - t : t;
         bid = skip ? 0 : bid;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
         // thresholds are >= 0 whenever project() runs (net.py:70); a negative one (3-D trainer, never projected)
         // sends the whole tile through the general shrinkage -- wave-uniform, so the common case pays 3 instructions
         // per element instead of 10
-        const bool tau_neg = MODE != MODE_BWD && __ballot(tau_s[lane] < 0.0f) != 0ull;
+        const bool tau_neg = MODE != MODE_BWD && __ballot(!(tau_s[lane] >= 0.0f)) != 0ull;   // negative OR NaN: the general, NaN-preserving form
 
         float ring[G][P];                                    // row-direction col2im sums, per group
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             const bool rowok = y < p.H;                          // uniform
             const bool valid = xok && rowok;
             const int voff = rowok ? voff_x : OOB;
-            const int voff_st = (p.dbg & 16) ? OOB : voff;
+            const int voff_st = CDL_DBG(p.dbg, 16) ? OOB : voff;
             // (y depends on the wave index: wave-uniform, but only readfirstlane makes that provable -- otherwise every
             //  buffer access below gets a waterfall loop around its scalar offset)
             const int s_row = __builtin_amdgcn_readfirstlane((int)((size_t)zd * HW + (size_t)y * p.W) * 4);
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
 
             // -- fat inputs of this block, issued first
             float zc[MT][16];
-            if (MODE != MODE_FIRST && (p.dbg & 8)) {
+            if (MODE != MODE_FIRST && CDL_DBG(p.dbg, 8)) {
 #pragma unroll
                 for (int R = 0; R < MT; ++R)
 #pragma unroll
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                 }
             }
             if (MODE == MODE_BWD && !p.do_synth) continue;
-            if (p.dbg & 4) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
+            if CDL_DBG(p.dbg, 4) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
             __builtin_amdgcn_sched_barrier(0);
             CDL_TL();
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
             for (int w = 0; w < NW; ++w) sacc += tacc_s[w * 64 + tid];
             if (tid < M) p.dtau[(size_t)tile * M + tid] = sacc;
         }
-        if ((MODE != MODE_BWD || p.do_synth) && !(p.dbg & 32)) {
+        if ((MODE != MODE_BWD || p.do_synth) && !CDL_DBG(p.dbg, 32)) {
             // tile patch = fixed-order sum (wave row, then wave column) of the wave patches covering each element;
             // CROWS patch rows per pass, one thread per element
             float *patch = p.patches + (size_t)tile * G * (PY * PX);
@@ -926,7 +926,7 @@ int dispatch(const cdl_geom *g, GParams &p, const Plan &pl, int mode, int precis
 {
     p.tl = g_timeline.load();
     p.rev = (precision >> 4) & 1;
-    p.dbg = cdl_opts().fused_debug;
+    CDL_DBG_FIELD(p.dbg = cdl_opts().fused_debug;)
     if ((precision >> 5) != 0) return CDL_EINVAL;
     if ((precision & 15) != 0) return CDL_EUNSUPPORTED;      // split-bf16 x3 only
     p.N = g->N; p.C = g->C; p.M = g->M; p.D = g->D; p.H = g->H; p.W = g->W; p.Pd = g->Pd;
@@ -1045,7 +1045,7 @@ int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *ma
     Plan pl;
     if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
-    if ((g->W & 3) == 0 && !(cdl_opts().fused_debug & 512)) {
+    if ((g->W & 3) == 0 && !cdl_opts().scalar_assemble) {
         dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
 #define CDL_ASM4(P_) k_assemble_g4<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
         if (pl.P == 3) CDL_ASM4(3); else if (pl.P == 5) CDL_ASM4(5); else CDL_ASM4(7);

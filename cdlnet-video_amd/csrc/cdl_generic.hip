@@ -800,9 +800,8 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
     size_t lds = (size_t)g->C * g->Pd * PH * PW * sizeof(float);
     if (lds > 160 * 1024) return CDL_EUNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_analysis,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
+        const int rc_ = cdl_ensure_dynamic_lds((const void *)k_analysis, (int)lds);
+        if (rc_) return rc_;
     }
     dim3 grid((unsigned)(tilesX * tilesY * Dz), (unsigned)g->N);
     k_analysis<<<grid, 256, lds, S(stream)>>>(*g, x, w, alpha, zin, gate, tau, out, tilesX, tilesY, px);
@@ -860,9 +859,8 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
     size_t lds = (size_t)MCHUNK * PZD * PZH * PZW * sizeof(float);
     if (lds > 160 * 1024) return CDL_EUNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_synthesis,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
+        const int rc_ = cdl_ensure_dynamic_lds((const void *)k_synthesis, (int)lds);
+        if (rc_) return rc_;
     }
     dim3 grid((unsigned)(tilesX * tilesY * g->D), (unsigned)g->N);
     k_synthesis<<<grid, 256, lds, S(stream)>>>(*g, z, gate, w, alpha, mask, sub, out, tilesX, tilesY,

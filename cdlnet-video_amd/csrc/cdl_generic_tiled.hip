@@ -738,9 +738,8 @@ int launch_analysis(const cdl_geom *g, const float *x, const float *w, float alp
     const size_t lds = (size_t)g->C * g->Pd * PH * PWp * sizeof(float);
     if (lds > 96 * 1024) return CDL_EUNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_analysis_t<PW, SW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
+        const int rc_ = cdl_ensure_dynamic_lds((const void *)k_analysis_t<PW, SW>, (int)lds);
+        if (rc_) return rc_;
     }
     int chunks;
     const int mper = channel_split(g->M, (long)tilesX * tilesY * Dz * g->N, &chunks);

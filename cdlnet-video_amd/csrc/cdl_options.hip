@@ -4,11 +4,11 @@
 //   * experiment / test switches, read from the environment ONCE (first use) into an immutable snapshot;
 //     cdl_options_reload() re-reads them (tests and tools flip a variable, then call it);
 //   * per-device facts: compute-unit count, and which kernels already had their dynamic-LDS limit raised
-//     on which device (hipFuncSetAttribute is per device: a second GPU in the same process needs its own call).
+//     and to how many bytes on which device (hipFuncSetAttribute is per device: a second GPU in the same process needs its own call).
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
-#include <set>
 #include <utility>
 
 #include "cdl_common.h"
@@ -40,15 +40,20 @@ const cdl_options *load_options()
     o->no_pipelined_synthesis = getenv("CDL_NO_PIPELINED_SYNTHESIS") ? 1 : 0;
     o->fused_snake = env_flag_off("CDL_FUSED_SNAKE");
     o->fused_grid = env_int("CDL_FUSED_GRID", 0);
+    o->scalar_assemble = env_int("CDL_SCALAR_ASSEMBLE", 0) ? 1 : 0;
+#ifdef CDL_ABLATE
     o->fused_debug = env_int("CDL_FUSED_DEBUG", 0);
     o->dense_debug = env_int("CDL_DENSE_DEBUG", 0);
+#else
+    o->fused_debug = o->dense_debug = 0;
+#endif
     return o;
 }
 
 constexpr int MAX_DEV = 64;
 std::atomic<int> g_cus[MAX_DEV];
 std::mutex g_attr_mutex;
-std::set<std::pair<int, const void *>> g_attr_done;
+std::map<std::pair<int, const void *>, int> g_attr_bytes;     // largest limit set so far per (device, kernel)
 
 }  // namespace
 
@@ -96,9 +101,12 @@ int cdl_ensure_dynamic_lds(const void *kernel, int bytes)
 {
     const int dev = cdl_current_device();
     std::lock_guard<std::mutex> lk(g_attr_mutex);
-    if (g_attr_done.count({dev, kernel})) return 0;
+    auto it = g_attr_bytes.find({dev, kernel});
+    if (it != g_attr_bytes.end() && it->second >= bytes) return 0;
+    // one template instantiation serves several LDS carvings (e.g. k_stage_g at M = 48 and M = 64): the limit
+    // must follow the LARGEST request, not the first
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return -(int)e;
-    g_attr_done.insert({dev, kernel});
+    g_attr_bytes[{dev, kernel}] = bytes;
     return 0;
 }

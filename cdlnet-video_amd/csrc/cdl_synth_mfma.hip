@@ -423,7 +423,7 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
         k_synth_m<PH, PW, SW, 0><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
     CDL_LAUNCH_CHECK();
     const size_t al = reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(mask) | reinterpret_cast<size_t>(sub);
-    if ((g->W & 3) == 0 && (al & 15) == 0 && !(cdl_opts().fused_debug & 512)) {     // (bit 512: the scalar form, for tests)
+    if ((g->W & 3) == 0 && (al & 15) == 0 && !cdl_opts().scalar_assemble) {     // (CDL_SCALAR_ASSEMBLE=1: the scalar form, for tests)
         dim3 grid4((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
         k_synth_assemble4<PH, PW, SW><<<grid4, 256, 0, st>>>(*g, patches, mask, sub, alpha, out, p.tilesX, p.tilesY);
         CDL_LAUNCH_CHECK();

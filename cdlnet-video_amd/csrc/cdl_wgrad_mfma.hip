@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned int pack_bf16(float a, float b)
 template <int PH, int PW, int SW, int NG, int CT>
 __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict__ F0,
                                              const float *__restrict__ gate, const float *__restrict__ x0,
-                                             float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP, int dbg,
+                                             float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP CDL_DBG_COMMA(int dbg),
                                              int ntiles, int tpw, const float *__restrict__ F1,
                                              const float *__restrict__ x1)
 {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             }
         };
         const int k0 = pp * kpw, k1 = (pp + 1) * kpw;       // kpw is a power of two >= 16
-        const bool pipelined = PREFETCH && active && fast && !(dbg & 2048);
+        const bool pipelined = PREFETCH && active && fast && !CDL_DBG(dbg, 2048);
         if constexpr (PREFETCH) {
             if (pipelined) {
 #pragma unroll
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         }
         __syncthreads();                                   // previous tile / previous batch's reduction has read the buffer
         if constexpr (EO) {
-            if (!(dbg & 1024)) {                           // (CDL_FUSED_DEBUG bits 1024 / 2048 / 4096: timing ablations)
+            if (!CDL_DBG(dbg, 1024)) {                           // (CDL_FUSED_DEBUG bits 1024 / 2048 / 4096: timing ablations)
                 constexpr int GS = NG * RT * CT * 16 <= 160 ? 2 : 1;   // groups in flight (registers next to acc)
 #pragma unroll
                 for (int gi = 0; gi < NG; gi += GS) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             }
         } else {
 #pragma unroll 1
-            for (int gi = 0; gi < ((dbg & 1024) ? 0 : NG); ++gi) {
+            for (int gi = 0; gi < (CDL_DBG(dbg, 1024) ? 0 : NG); ++gi) {
                 const int grp = g0 + gi;
                 const int kd = grp % g.Pd, c = grp / g.Pd;
                 const int d = zd * g.sd - g.pd + kd;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 }
             }
         }
-        if (active && !pipelined && !(dbg & 2048)) {
+        if (active && !pipelined && !CDL_DBG(dbg, 2048)) {
 #pragma unroll 1
             for (int ks = pp * kpw; ks < (pp + 1) * kpw; ++ks) {
                 const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;       // tile-local pixels zx0 .. zx0+7 of row zy
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         //      partial[tile][grp][tap][m]; register v of tile (R, q) is tap 32R + 8(v>>2) + 4h + (v&3) of channel
         //      32(CT cg + q) + l32.  Fixed order: deterministic.  (The first version made 2 barriers and a strided
         //      8-term sum per accumulator tile: 25 of the 100 us of a cfg3 launch.)
-        if (!(dbg & 4096)) {
+        if (!CDL_DBG(dbg, 4096)) {
             constexpr int NT = NG * RT * CT;
             constexpr int LDS_BYTES = NG * (EO ? 4 * PD * 4 : XE * 4) > 32768 ? NG * (EO ? 4 * PD * 4 : XE * 4) : 32768;
             constexpr int TPR = LDS_BYTES / (4 * 4096) < NT ? LDS_BYTES / (4 * 4096) : NT;   // tiles per round
@@ -503,7 +503,7 @@ int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gat
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
     k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1), GNT, p.lds, st>>>(
-        *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP, cdl_opts().fused_debug & (1024 | 2048 | 4096), (int)p.tiles,
+        *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP CDL_DBG_COMMA(cdl_opts().fused_debug & (1024 | 2048 | 4096)), (int)p.tiles,
         p.tpw, F1, x1);
     CDL_LAUNCH_CHECK();
     return 0;

@@ -18,14 +18,17 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _first_cuda_tensor(args, kwargs):
-    for a in list(args) + list(kwargs.values()):
-        if torch.is_tensor(a) and a.is_cuda:
-            return a
-        if isinstance(a, (list, tuple)):
-            for b in a:
-                if torch.is_tensor(b) and b.is_cuda:
-                    return b
+def _first_cuda_tensor(args, kwargs=None):
+    """First CUDA tensor among the arguments, searching nested lists / tuples to any depth (gabor_filter_banks takes
+    a list of 4-tuples of tensors)."""
+    for a in list(args) + (list(kwargs.values()) if kwargs else []):
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return a
+        elif isinstance(a, (list, tuple)):
+            t = _first_cuda_tensor(a)
+            if t is not None:
+                return t
     return None
 
 

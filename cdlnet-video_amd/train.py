@@ -161,6 +161,12 @@ def fit(net, opt, loaders, sched=None, epochs=1, device=torch.device("cpu"), sav
       is nan/inf, reload `net.ckpt` (`0.ckpt` while `epoch <= save_freq`), scale every learning rate by 0.8,
       rewind `epoch` to the checkpointed one and log it in `backtrack.txt`;
     * scheduler step per epoch; `net.ckpt` (+ `epoch_fun(epoch)`) every `save_freq` epochs; `0.ckpt` at start.
+      Under data parallelism `epoch_fun` runs on RANK 0 ONLY, between the checkpoint write and the barrier: it is
+      for rank-0 side effects (plots, copies of the checkpoint).  It must not change the net or the optimiser and
+      must not issue a collective -- either would desynchronise or deadlock the replicas.
+    * like the reference (train.py:113-142) the backtracking loop has NO bound: when the reloaded checkpoint
+      itself cannot recover (e.g. a learning rate that diverges from `0.ckpt` at any scale the decay reaches
+      within float range), `fit` repeats the epoch with lr x 0.8 indefinitely.
 
     `loaders` maps phase -> iterable of clean batches.  `generator` (new): the torch.Generator every noise draw uses;
     a CPU generator (torch.default_generator after torch.manual_seed) reproduces the random stream of the reference's

@@ -451,7 +451,7 @@ def test_bf16_code_storage_keeps_psnr_to_2dp():
 
 def test_assemble_vector_form_is_bit_identical(hip_env):
     """k_assemble_v4 (batches, W % 4 == 0: 4 pixels x 2 rows per thread, 16-byte thin accesses) against the scalar form
-    (CDL_FUSED_DEBUG bit 512 selects it): same sums in the same order."""
+    (CDL_SCALAR_ASSEMBLE=1 selects it): same sums in the same order."""
     import cdlnet_video_amd as cva
     o = cva.ops
     N, M, P, H, W = 16, 32, 7, 256, 256
@@ -461,7 +461,40 @@ def test_assemble_vector_form_is_bit_identical(hip_env):
     yp = torch.randn(N, 1, H, W, device="cuda", generator=gen)
     mask = (torch.rand(N, 1, H, W, device="cuda", generator=gen) < 0.5).float()
     outs = []
-    for dbg in ("0", "512"):
-        hip_env("CDL_FUSED_DEBUG", dbg)
+    for dbg in ("0", "1"):
+        hip_env("CDL_SCALAR_ASSEMBLE", dbg)
         outs.append((o.fused_assemble(geom, patches, mask, yp, 1.0), o.fused_assemble(geom, patches, None, None, -1.0)))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_nan_threshold_yields_nan_codes_in_every_fused_kernel():
+    """a NaN threshold (diverged t, or NaN sigma) must come out as NaN codes -- sign(u)*relu(|u|-NaN) is
+    NaN in the reference (model/net.py:11-14) -- so that fit()'s nan/inf backtracking sees it.  The clamp fast path
+    u - med3(u,-t,t) would give 0; a NaN threshold therefore takes the general form (wave-uniform predicate
+    !(tau >= 0))."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    gen = torch.Generator().manual_seed(5)
+    # fused 2-D kernel
+    N, M, P, H, W = 2, 64, 7, 24, 70
+    geom = o.Geometry.make(N, 1, M, (H, W), (P, P), (P // 2, P // 2), 1)
+    r = torch.randn(N, 1, H, W, generator=gen).cuda()
+    z = torch.randn(N, M, H, W, generator=gen).cuda()
+    wA = (torch.randn(M, 1, P, P, generator=gen) * 0.15).cuda()
+    tau = torch.full((N, M), 0.05).cuda()
+    tau[1, 17] = float("nan")
+    frags = o.fused_prep(wA, wA)
+    patches = o.fused_patches(geom, "cuda")
+    got = o.fused_iter(geom, r, z, tau, frags, -1.0, patches, "split3")
+    assert torch.isnan(got[1, 17]).all() and not torch.isnan(got[0]).any() and not torch.isnan(got[1, :17]).any()
+    ref = o.analysis(geom, r, wA, -1.0, z, None, tau)            # matrix-core analysis tier (k_ana_m)
+    assert torch.isnan(ref[1, 17]).all() and not torch.isnan(ref[0]).any()
+    # fused generic kernel (3-D)
+    g3 = o.Geometry.make(1, 1, 48, (4, 16, 64), (5, 5, 5), (2, 2, 2), 1)
+    r3 = torch.randn(g3.image_shape(), generator=gen).cuda()
+    z3 = torch.randn(g3.code_shape(), generator=gen).cuda()
+    w3 = (torch.randn(g3.filter_shape(), generator=gen) * 0.1).cuda()
+    tau3 = torch.full((1, 48), 0.05).cuda()
+    tau3[0, 5] = float("nan")
+    got3 = o.fusedg_iter(g3, r3, z3, tau3, o.fusedg_prep(g3, w3, w3), -1.0, o.fusedg_patches(g3, "cuda"))
+    assert torch.isnan(got3[0, 5]).all() and not torch.isnan(got3[0, :5]).any() and not torch.isnan(got3[0, 6:]).any()

@@ -158,8 +158,8 @@ def test_fusedg_sweeps_equal_generic_on_same_activations(kind, kw, shape, masked
 
 
 def test_fusedg_assemble_vector_form_is_bit_identical(hip_env):
-    """k_assemble_g4 (W % 4 == 0: 4 pixels per thread, 16-byte thin accesses) against the scalar form (CDL_FUSED_DEBUG
-    bit 512): same sums in the same order."""
+    """k_assemble_g4 (W % 4 == 0: 4 pixels per thread, 16-byte thin accesses) against the scalar form
+    (CDL_SCALAR_ASSEMBLE=1): same sums in the same order."""
     import cdlnet_video_amd as cva
     o = cva.ops
     for N, C, M, sp, P in ((2, 1, 48, (6, 40, 72), (5, 5, 5)), (1, 3, 64, (36, 132), (7, 7))):
@@ -169,8 +169,8 @@ def test_fusedg_assemble_vector_form_is_bit_identical(hip_env):
         yp = torch.randn(g.image_shape(), device="cuda", generator=gen)
         mask = (torch.rand(g.image_shape(), device="cuda", generator=gen) < 0.5).float()
         outs = []
-        for dbg in ("0", "512"):
-            hip_env("CDL_FUSED_DEBUG", dbg)
+        for dbg in ("0", "1"):
+            hip_env("CDL_SCALAR_ASSEMBLE", dbg)
             outs.append((o.fusedg_assemble(g, patches, mask, yp, 1.0), o.fusedg_assemble(g, patches, None, None, -1.0)))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
@@ -207,3 +207,21 @@ def test_fusedg_timeline_hook_records_and_does_not_disturb(hip_env):
     o.fusedg_iter(g, r, z, tau, frags, -1.0, patches)
     torch.cuda.synchronize()
     assert int(tl.abs().sum()) == 0
+
+
+def test_one_instantiation_serves_a_larger_lds_carving_after_a_smaller_one():
+    """k_stage_g<P,G,MT,MODE> takes its dynamic-LDS size from M (KQ = ceil(M/16)); M = 48 needs
+    ~138 KB, M = 64 ~148 KB with the same template arguments.  The launcher must raise the kernel's limit when a
+    LARGER request follows a smaller one in the same process (cdl_ensure_dynamic_lds keeps the maximum)."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    gen = torch.Generator().manual_seed(11)
+    for M in (40, 48, 56, 64):                       # ascending: every step asks for more LDS than the last
+        g = make_geom(1, 1, M, (5, 16, 64), (5, 5, 5))
+        assert o.fusedg_supported(g)
+        r = torch.randn(g.image_shape(), generator=gen).cuda()
+        z = (torch.randn(g.code_shape(), generator=gen) * 0.3).cuda()
+        w = (torch.randn(g.filter_shape(), generator=gen) * 0.1).cuda()
+        tau = torch.full((1, M), 0.05).cuda()
+        got = o.fusedg_iter(g, r, z, tau, o.fusedg_prep(g, w, w), -1.0, o.fusedg_patches(g, "cuda"))
+        check(f"fusedg LDS growth M{M}", got, o.analysis(g, r, w, -1.0, z, None, tau), 2e-5)

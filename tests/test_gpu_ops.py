@@ -292,15 +292,15 @@ def test_bad_arguments_fail_loudly():
 
 def test_synthesis_assemble_vector_form_is_bit_identical(hip_env):
     """k_synth_assemble4 (W % 4 == 0: 4 pixels per thread, 16-byte thin accesses) against the scalar form
-    (CDL_FUSED_DEBUG bit 512): same terms in the same order, stride 1 and 2, 2-D and 3-D."""
+    (CDL_SCALAR_ASSEMBLE=1): same terms in the same order, stride 1 and 2, 2-D and 3-D."""
     o = ops()
     for N, C, M, sp, P, s in ((24, 3, 5, (40, 72), (7, 7), 1), (48, 1, 6, (132, 72), (7, 7), 2), (3, 1, 5, (9, 40, 72), (5, 5, 5), 1)):
         x, z, w = make(N, C, M, sp, P, s, seed=5)
         geom = o.Geometry.make(N, C, M, sp, P, tuple(p // 2 for p in P), s)
         mask = (torch.rand(x.shape) < 0.5).float().cuda()
         outs = []
-        for dbg in ("0", "512"):
-            hip_env("CDL_FUSED_DEBUG", dbg)
+        for dbg in ("0", "1"):
+            hip_env("CDL_SCALAR_ASSEMBLE", dbg)
             outs.append(o.synthesis(geom, z.cuda(), w.cuda(), -1.5, None, mask, x.cuda()))
         assert torch.equal(outs[0], outs[1]), (N, C, M, sp, P, s)
 

@@ -100,3 +100,27 @@ def test_net_on_a_non_current_device():
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError):                      # tensors of one call on two devices
         net.to("cuda:1")(y.to("cuda:0"), 25.0)
+    # a Gabor net (its bank synthesis takes NESTED tuples of tensors) and a dense-tier block on cuda:1.
+    # NOTE: this pool's boxes have one GPU, so everything below the skip has not run on hardware.
+    torch.manual_seed(1)
+    gd = cva.GDLNet(K=2, M=32, P=7, s=1, C=1, t0=5e-3, order=1, adaptive=True, init=False)
+    ref = [t.detach().cpu() for t in gd.to("cuda:0")(y.to("cuda:0"), 25.0)]
+    assert torch.cuda.current_device() == 0
+    got = [t.detach().cpu() for t in gd.to("cuda:1")(y.to("cuda:1"), 25.0)]
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    xb = torch.randn(1, 32, 3, 12, 40) * 0.5
+    w1, w2 = torch.randn(32, 32, 3, 3, 3) / 30, torch.randn(32, 32, 3, 3, 3) / 30
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        gb = cva.ops.residual_geometry(xb, w1)
+        outs.append(cva.ops.residual_forward(gb, xb.to(dev), w1.to(dev), w2.to(dev))[1].cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_device_lookup_searches_nested_sequences():
+    import cdlnet_video_amd as cva
+    t = torch.zeros(1, device="cuda")
+    c = torch.zeros(1)
+    assert cva.ops._first_cuda_tensor(([(c, c, c, c), (c, t, c, c)], 7, (1, 2)), {}) is t
+    assert cva.ops._first_cuda_tensor((c, [c, (c,)]), {"k": [c]}) is None
+    assert cva.ops._first_cuda_tensor((c,), {"k": [[t]]}) is t

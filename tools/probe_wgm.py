@@ -8,6 +8,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'probes' else '.'))
+import _ablate                                  # noqa: E402,F401  (probe build of the library)
 import torch                                    # noqa: E402
 import cdlnet_video_amd as cva                  # noqa: E402
 

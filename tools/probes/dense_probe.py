@@ -4,6 +4,8 @@ epilogue / LDS stores; results are NOT valid when set, timing only).  `dense_pro
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'probes' else '.'))
+import _ablate                                  # noqa: E402,F401  (probe build of the library)
 import torch
 import cdlnet_video_amd as cva
 o = cva.ops
