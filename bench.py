@@ -327,6 +327,8 @@ def run_rank(args):
     fwd_mpix = B * S * S / (fwd_ms * 1e-3) / 1e6
 
     out = None
+    syncs_per_step = (bucket.syncs / max(args.steps + args.warmup, 1)) if world > 1 else 0
+    bucket.detach()          # the kernel probes below re-run steps on rank 0 ALONE: no collective may be issued there
     if rank == 0:
         note(f"fwd-only {fwd_ms:.1f} ms; probing kernels")
         rows, dom = kernel_probe(cva, net, B, S)
@@ -372,7 +374,7 @@ def run_rank(args):
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "rccl_world": dist.get_world_size() if world > 1 else 1,
             "dist_backend": (dist.get_backend() if world > 1 else None),
-            "grad_syncs_per_step": (bucket.syncs / max(args.steps + args.warmup, 1)) if world > 1 else 0,
+            "grad_syncs_per_step": syncs_per_step,
             "fwd_only_mpix_s": round(fwd_mpix, 3), "fwd_ms": round(fwd_ms, 3),
             "loss": float(loss),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(d["GBps"], 2),

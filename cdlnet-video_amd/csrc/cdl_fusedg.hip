@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "cdl_common.h"
+#include "cdl_strip.h"
 
 namespace {
 
@@ -972,42 +973,56 @@ int cdl_fusedg_set_timeline(void *buf)
     return 0;
 }
 
+/* Shapes outside plan_for() that the strip kernel takes (cdl_strip.hip: one image channel, stride 1 or 2, up to 192
+ * subbands -- the shipped CDLNet-s2030 architecture) go through the same entry points. */
 int cdl_fusedg_supported(const cdl_geom *g)
 {
     Plan pl;
-    return plan_for(g, &pl) ? 1 : 0;
+    cdl_strip_plan sp;
+    return (plan_for(g, &pl) || cdl_strip_plan_for(g, &sp)) ? 1 : 0;
 }
 
 size_t cdl_fusedg_frag_bytes(const cdl_geom *g)
 {
     Plan pl;
-    return plan_for(g, &pl) ? pl.frag_uint4 * 16 : 0;
+    cdl_strip_plan sp;
+    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.frag_uint4 * 16 : 0;
+    return pl.frag_uint4 * 16;
 }
 
 size_t cdl_fusedg_patch_floats(const cdl_geom *g)
 {
     Plan pl;
-    return plan_for(g, &pl) ? pl.patch_floats : 0;
+    cdl_strip_plan sp;
+    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.patch_floats : 0;
+    return pl.patch_floats;
 }
 
 size_t cdl_fusedg_tiles(const cdl_geom *g)
 {
     Plan pl;
-    return plan_for(g, &pl) ? pl.tiles : 0;
+    cdl_strip_plan sp;
+    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.items : 0;
+    return pl.tiles;
 }
 
 size_t cdl_fusedg_map_words(const cdl_geom *g)
 {
     Plan pl;
-    return plan_for(g, &pl) ? (size_t)g->N * 4 * g->D * g->H * g->W : 0;
+    cdl_strip_plan sp;
+    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.map_words : 0;
+    return (size_t)g->N * 4 * g->D * g->H * g->W;
 }
 
 int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!wA || !wB || !frags) return CDL_EINVAL;
     const float *a[1] = {wA}, *b[1] = {wB};
+    if (strip) return cdl_strip_prep_pairs(g, sp, a, b, 1, 1, frags, S(stream));
     return prep_pairs(g, pl, a, b, 1, 1, frags, S(stream));
 }
 
@@ -1015,8 +1030,16 @@ int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin, con
                         float sgn, float *zout, float *patches, unsigned *map_out, int precision, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
+    if (strip) {
+        if ((precision >> 5) != 0) return CDL_EINVAL;
+        if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
+        return cdl_strip_stage(g, sp, zin ? 0 : 1, r, zin, tau, frags, sgn, zout, patches, map_out, nullptr, 1,
+                               (precision >> 4) & 1, S(stream));
+    }
     GParams p = {};
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
     p.frags = reinterpret_cast<const uint4 *>(frags);
@@ -1029,9 +1052,17 @@ int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base
                          int precision, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
+    if (strip) {
+        if ((precision >> 5) != 0) return CDL_EINVAL;
+        if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
+        return cdl_strip_stage(g, sp, 2, thin, base, nullptr, frags, 1.0f, du_out, patches, const_cast<unsigned *>(map),
+                               dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, S(stream));
+    }
     GParams p = {};
     p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
     p.frags = reinterpret_cast<const uint4 *>(frags);
@@ -1043,8 +1074,11 @@ int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *ma
                         float *out, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!patches || !out) return CDL_EINVAL;
+    if (strip) return cdl_strip_assemble(g, sp, patches, mask, sub, alpha, out, S(stream));
     if ((g->W & 3) == 0 && !cdl_opts().scalar_assemble) {
         dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
 #define CDL_ASM4(P_) k_assemble_g4<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
@@ -1064,10 +1098,12 @@ int cdl_fusedg_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const f
                            void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
-    k_dtau_reduce_g<<<(g->M + 3) / 4, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N,
-                                                            g->D * pl.tilesX * pl.tilesY, g->M);
+    const int per_img = strip ? sp.nsx * sp.nsy : g->D * pl.tilesX * pl.tilesY;
+    k_dtau_reduce_g<<<(g->M + 3) / 4, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, per_img, g->M);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1078,13 +1114,16 @@ int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *m
                        unsigned *const *maps, float *xp, void *frags, float *patches, int precision, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
     const size_t nm = (size_t)g->N * g->M;
     const int snake = cdl_opts().fused_snake;
     const float *thin = yp;
-    const size_t fb = pl.frag_uint4 * 16;
-    int rc = prep_pairs(g, pl, wA, wB, K, 1, frags, S(stream));             // (A_k, B_{k+1}) for every k
+    const size_t fb = (strip ? sp.frag_uint4 : pl.frag_uint4) * 16;
+    int rc = strip ? cdl_strip_prep_pairs(g, sp, wA, wB, K, 1, frags, S(stream))
+                   : prep_pairs(g, pl, wA, wB, K, 1, frags, S(stream));     // (A_k, B_{k+1}) for every k
     if (rc) return rc;
     for (int k = 0; k < K; ++k) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
@@ -1112,7 +1151,9 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
                         float *dtau_partial, float *wgrad_ws, size_t wgrad_ws_floats, int precision, void *stream)
 {
     Plan pl;
-    if (!plan_for(g, &pl)) return CDL_EUNSUPPORTED;
+    cdl_strip_plan sp;
+    const bool strip = !plan_for(g, &pl);
+    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (K < 1 || !yp || !wA || !wB || !z || !maps || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
         !patches || !dtau_partial || (K > 1 && !r))
         return CDL_EINVAL;
@@ -1123,8 +1164,9 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
     int rc = cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], wgrad_ws, wgrad_ws_floats, stream);      // dB_0 = z_K (x) dL/d(D z_K)
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
-    const size_t fb = pl.frag_uint4 * 16;
-    rc = prep_pairs(g, pl, wB, wA, K, 0, frags, S(stream));                 // (B_{k+1}, A_k) for every k
+    const size_t fb = (strip ? sp.frag_uint4 : pl.frag_uint4) * 16;
+    rc = strip ? cdl_strip_prep_pairs(g, sp, wB, wA, K, 0, frags, S(stream))
+               : prep_pairs(g, pl, wB, wA, K, 0, frags, S(stream));         // (B_{k+1}, A_k) for every k
     if (rc) return rc;
     for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;

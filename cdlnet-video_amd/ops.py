@@ -782,7 +782,9 @@ def fused_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt
 
 # ------------------------------------------------------------------------------------------ fused generic path
 # cdl_fusedg.hip: the fused iteration for any C, 2-D / 3-D, unit stride, P in {3,5,7}, M <= 64 (BASELINE configs[2]
-# and [3]); same call structure as the 2-D flagship path above, codes in the reference's (N,M,[D,]H,W) layout.
+# and [3]), and -- behind the same entry points -- cdl_strip.hip: one image channel, stride 1 or 2, up to 192 subbands
+# (the shipped CDLNet-s2030 architecture); same call structure as the 2-D flagship path above, codes in the
+# reference's (N,M,[D,]H,W) layout.
 def fusedg_supported(g: Geometry) -> bool:
     gs = g.c_struct()
     return bool(_lib.lib().cdl_fusedg_supported(ctypes.byref(gs)))
@@ -795,8 +797,19 @@ def _fusedg_sizes(g: Geometry):
             int(L.cdl_fusedg_tiles(ctypes.byref(gs))), int(L.cdl_fusedg_map_words(ctypes.byref(gs))))
 
 
+def _fusedg_map_shape(g: Geometry):
+    """(N, planes) + code dims.  The tile kernel (unit stride, M <= 64): 4 planes; the strip kernel (cdl_strip.hip): 4
+    planes per PAIR of 32-channel tiles, on the code grid."""
+    mw = _fusedg_sizes(g)[3]
+    sp = tuple(d // st for d, st in zip(g.dims, g.stride))          # (Dz, Hz, Wz), leading 1 for 2-D
+    per = 1
+    for d in sp:
+        per *= d
+    return (g.N, mw // (g.N * per)) + sp
+
+
 def fusedg_map(g: Geometry, device):
-    return torch.empty((g.N, 4) + tuple(g.dims), device=device, dtype=torch.int32)
+    return torch.empty(_fusedg_map_shape(g), device=device, dtype=torch.int32)
 
 
 def fusedg_prep(g: Geometry, wA, wB):
@@ -835,20 +848,25 @@ def fusedg_assemble(g: Geometry, patches, mask=None, sub=None, alpha=1.0, out=No
 
 
 def fusedg_support_map(g: Geometry, z):
-    """Bit map of a code tensor in the layout the fused stages use: (N, 4, D, H, W) words, plane 2h = [z != 0], plane
-    2h + 1 = sign bit, bit 16R + v = channel 32R + 8(v>>2) + 4h + (v&3) (host-side plumbing for tests)."""
+    """Bit map of a code tensor in the layout the fused stages use: (N, 4 * pairs, code dims) words; channel
+    32R + 8q + 4h + e is bit 16(R&1) + 4q + e of plane 4(R>>1) + 2h (support, [z != 0]) and of plane 4(R>>1) + 2h + 1
+    (sign bit, set only where there is support) -- one plane quadruple per pair of 32-channel tiles (M <= 64: the 4 planes of the tile kernel).
+    Host-side plumbing for tests."""
     z = _dev(z, "z")
     N, M = z.shape[:2]
-    sp = tuple(g.dims)
+    shape = _fusedg_map_shape(g)
+    sp = shape[2:]
     zz = z.reshape((N, M) + sp)
-    out = torch.zeros((N, 4) + sp, device=z.device, dtype=torch.int64)
+    out = torch.zeros(shape, device=z.device, dtype=torch.int64)
     for ch in range(M):
         R, rem = divmod(ch, 32)
         q, rem = divmod(rem, 8)
         h, e = divmod(rem, 4)
-        bit = 16 * R + 4 * q + e
-        out[:, 2 * h] |= (zz[:, ch] != 0).to(torch.int64) << bit
-        out[:, 2 * h + 1] |= (torch.signbit(zz[:, ch])).to(torch.int64) << bit
+        bit = 16 * (R & 1) + 4 * q + e
+        pl = 4 * (R >> 1) + 2 * h
+        nz = zz[:, ch] != 0
+        out[:, pl] |= nz.to(torch.int64) << bit
+        out[:, pl + 1] |= (torch.signbit(zz[:, ch]) & nz).to(torch.int64) << bit
     out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
     return out.to(torch.int32).contiguous()
 
@@ -888,7 +906,7 @@ def fusedg_forward(g: Geometry, yp, mask_p, tau, A, B, keep):
     rbuf = torch.empty((max(nr, 1),) + g.image_shape(), device=dev, dtype=torch.float32)
     z = [zbuf[k % nz] for k in range(K)]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
-    maps = list(torch.empty((K, g.N, 4) + tuple(g.dims), device=dev, dtype=torch.int32).unbind(0)) if keep else []
+    maps = list(torch.empty((K,) + _fusedg_map_shape(g), device=dev, dtype=torch.int32).unbind(0)) if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
     frags = torch.empty(K * fb, device=dev, dtype=torch.uint8)
     patches = torch.empty(pf, device=dev, dtype=torch.float32)

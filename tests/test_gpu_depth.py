@@ -215,3 +215,64 @@ def test_cfg2_full_batch_64x256x256():
     log(f"cfg2 full batch 64x256x256: PSNR ref={p_ref:.4f} ours={p_got:.4f} noisy={O.psnr(x[pick], y[pick]):.2f} "
         f"whole batch {O.psnr(x, xhat.cpu()):.4f}")
     assert round(p_ref, 2) == round(p_got, 2) and O.psnr(x, xhat.cpu()) > O.psnr(x, y)
+
+
+def test_cfg3_full_batch_8_clips_8x128x128():
+    """configs[2] at its FULL size (CDLNetVideo K=20 M=48 P=5x5x5, 8 clips of 1x8x128x128) through the fused 3-D
+    sweep: (i) the batched result equals single-clip runs bit for bit, (ii) two clips match the CPU oracle to 1e-5
+    with PSNR equal to 2 dp, (iii) everything is finite and denoising gains PSNR."""
+    import cdlnet_video_amd as cva
+    torch.manual_seed(3)
+    K, M, P = 20, 48, [5, 5, 5]
+    net = cva.CDLNetVideo(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, depth=8, init=True)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    shape = (8, 1, 8, 128, 128)
+    g = cva.ops.Geometry.make(8, 1, M, shape[2:], tuple(P), (2, 2, 2), 1)
+    assert cva.ops.fusedg_supported(g) and cva.loop.BACKEND == "auto"
+    x = cva.utils.synthetic_clip(shape, seed=30)
+    y = x + torch.randn(shape, generator=torch.Generator().manual_seed(130)) * 25.0 / 255
+    with torch.no_grad():
+        xhat, z = net(y.cuda(), 25.0)
+        for n in (0, 5, 7):
+            xn, zn = net(y[n:n + 1].cuda(), 25.0)
+            assert torch.equal(xn, xhat[n:n + 1]) and torch.equal(zn, z[n:n + 1]), n
+    assert torch.isfinite(xhat).all() and torch.isfinite(z).all()
+    pick = [0, 7]
+    xr, _ = O.ista(sd, y[pick], K=K, P=tuple(P), s=1, sigma=25.0, adaptive=True, ndim=3)
+    check("cfg3 full batch: clips 0 and 7 vs oracle", xhat[pick], xr, XTOL)
+    p_ref, p_got = O.psnr(x[pick], xr), O.psnr(x[pick], xhat[pick].cpu())
+    log(f"cfg3 full batch 8x1x8x128x128: PSNR ref={p_ref:.4f} ours={p_got:.4f} noisy={O.psnr(x[pick], y[pick]):.2f} "
+        f"whole batch {O.psnr(x, xhat.cpu()):.4f}")
+    assert round(p_ref, 2) == round(p_got, 2) and O.psnr(x, xhat.cpu()) > O.psnr(x, y)
+
+
+def test_cfg4_full_batch_8x3x256x256_bayer():
+    """configs[3] at its FULL size (JDD CDLNet K=42 M=64 P=7 C=3, 8 x 3 x 256 x 256, Bayer mask, sigma ~ U(1,20) per
+    sample): batched == single-sample bit for bit, two samples against the oracle at 1e-5, PSNR to 2 dp."""
+    import cdlnet_video_amd as cva
+    torch.manual_seed(4)
+    K, M, P = 42, 64, 7
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=3, t0=5e-3, adaptive=True, init=True)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    shape = (8, 3, 256, 256)
+    g = cva.ops.Geometry.make(8, 3, M, shape[2:], (P, P), (3, 3), 1)
+    assert cva.ops.fusedg_supported(g) and cva.loop.BACKEND == "auto"
+    x = cva.utils.synthetic_clip(shape, seed=40)
+    m = cva.gen_bayer_mask(x)
+    noisy, sig = cva.awgn(x, (1, 20), torch.Generator().manual_seed(140))
+    y = m * noisy
+    with torch.no_grad():
+        xhat, z = net(y.cuda(), sig.cuda(), mask=m.cuda())
+        for n in (0, 3, 7):
+            xn, zn = net(y[n:n + 1].cuda(), sig[n:n + 1].cuda(), mask=m[n:n + 1].cuda())
+            assert torch.equal(xn, xhat[n:n + 1]) and torch.equal(zn, z[n:n + 1]), n
+    assert torch.isfinite(xhat).all() and torch.isfinite(z).all()
+    pick = [0, 7]
+    xr, _ = O.ista(sd, y[pick], K=K, P=P, s=1, sigma=sig[pick], adaptive=True, mask=m[pick])
+    check("cfg4 full batch: samples 0 and 7 vs oracle", xhat[pick], xr, XTOL)
+    p_ref, p_got = O.psnr(x[pick], xr), O.psnr(x[pick], xhat[pick].cpu())
+    log(f"cfg4 full batch 8x3x256x256 + Bayer: PSNR ref={p_ref:.4f} ours={p_got:.4f} observed={O.psnr(x[pick], y[pick]):.2f} "
+        f"whole batch {O.psnr(x, xhat.cpu()):.4f}")
+    assert round(p_ref, 2) == round(p_got, 2) and O.psnr(x, xhat.cpu()) > O.psnr(x, y)

@@ -62,7 +62,7 @@ def test_bench_gpus_2_runs_two_ranks_and_reports_them():
     env["CDL_DIST_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2",
                         "--warmup", "1", "--batch", "4", "--size", "128", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
