@@ -80,6 +80,7 @@ SIGNATURES = {
     "cdl_fused2d_forward": [_G, _I] + [_P] * 11 + [_I, _P],
     "cdl_fused2d_backward": [_G, _I] + [_P] * 20 + [_I, _P],
     "cdl_fusedg_supported": [_G],
+    "cdl_fusedg_code_layout": [_G],
     "cdl_fusedg_set_timeline": [_P],
     "cdl_fusedg_prep": [_G, _P, _P, _P, _P],
     "cdl_fusedg_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
@@ -89,7 +90,7 @@ SIGNATURES = {
     "cdl_fusedg_forward": [_G, _I] + [_P] * 11 + [_I, _P],
     "cdl_fusedg_backward": [_G, _I] + [_P] * 20 + [ctypes.c_size_t, _I, _P],
 }
-SIZE_T_FUNCS = {"cdl_fusedg_frag_bytes": [_G], "cdl_fusedg_patch_floats": [_G], "cdl_fusedg_tiles": [_G],
+SIZE_T_FUNCS = {"cdl_fusedg_code_floats": [_G, _I], "cdl_fusedg_frag_bytes": [_G], "cdl_fusedg_patch_floats": [_G], "cdl_fusedg_tiles": [_G],
                 "cdl_fusedg_map_words": [_G], "cdl_fused2d_frag_bytes": [_I], "cdl_fused2d_patch_floats": [_G], "cdl_fused2d_code_bytes": [_G, _I],
                 "cdl_fused2d_tiles": [_G], "cdl_fused2d_map_words": [_G], "cdl_fused2d_wgrad_workspace_floats": [_G],
                 "cdl_wgrad_workspace_floats": [_G], "cdl_prox_csr_scratch_floats": [_G],

@@ -167,5 +167,11 @@ int cdl_mfma_wgrad(const cdl_geom *g, const float *F, const float *gate, const f
 int cdl_mfma_wgrad_pair(const cdl_geom *g, const float *F0, const float *x0, float alpha0, float *dw0, const float *F1,
                         const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats, void *stream);
 size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g);
+bool cdl_mfma_wgrad_takes(const cdl_geom *g);
+int cdl_mfma_wgrad_lay(const cdl_geom *g, const float *F, const float *x, float alpha, float *dw, float *ws,
+                       size_t ws_floats, int rsc, void *stream);
+int cdl_mfma_wgrad_pair_lay(const cdl_geom *g, const float *F0, const float *x0, float alpha0, float *dw0,
+                            const float *F1, const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats,
+                            int rsc, void *stream);
 int cdl_tiled_wgrad(const cdl_geom *g, const float *z, const float *gate, const float *x, float alpha,
                     float *dw, float *workspace, size_t workspace_floats, void *stream);

@@ -961,6 +961,17 @@ int prep_pairs(const cdl_geom *g, const Plan &pl, const float *const *w1, const 
     return 0;
 }
 
+// layouts of the strip kernel's fat operands from the precision word: CDL_LAY_NCHW or CDL_LAY_RSC on either side
+bool strip_layouts(int precision, int *lay_in, int *lay_out)
+{
+    const int li = (precision >> 5) & 3, lo = (precision >> 7) & 3;
+    if ((precision >> 9) != 0) return false;
+    if ((li != CDL_LAY_NCHW && li != CDL_LAY_RSC) || (lo != CDL_LAY_NCHW && lo != CDL_LAY_RSC)) return false;
+    *lay_in = li == CDL_LAY_RSC;
+    *lay_out = lo == CDL_LAY_RSC;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1014,6 +1025,24 @@ size_t cdl_fusedg_map_words(const cdl_geom *g)
     return (size_t)g->N * 4 * g->D * g->H * g->W;
 }
 
+/* The layout the sweeps should keep z[0..K-2] and the du buffers in: CDL_LAY_RSC for the strip kernel's shapes when the
+ * matrix-core filter-gradient kernel takes the geometry, CDL_LAY_NCHW otherwise; cdl_fusedg_code_floats: floats of one
+ * code tensor in that layout. */
+int cdl_fusedg_code_layout(const cdl_geom *g)
+{
+    Plan pl;
+    cdl_strip_plan sp;
+    if (plan_for(g, &pl) || !cdl_strip_plan_for(g, &sp)) return CDL_LAY_NCHW;
+    return cdl_mfma_wgrad_takes(g) ? CDL_LAY_RSC : CDL_LAY_NCHW;
+}
+
+size_t cdl_fusedg_code_floats(const cdl_geom *g, int layout)
+{
+    cdl_strip_plan sp;
+    if (layout == CDL_LAY_RSC) return cdl_strip_plan_for(g, &sp) ? cdl_strip_rsc_floats(g, sp) : 0;
+    return (size_t)g->N * g->M * (g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
+}
+
 int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream)
 {
     Plan pl;
@@ -1035,10 +1064,11 @@ int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin, con
     if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
     if (strip) {
-        if ((precision >> 5) != 0) return CDL_EINVAL;
+        int li, lo;
+        if (!strip_layouts(precision, &li, &lo)) return CDL_EINVAL;
         if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
         return cdl_strip_stage(g, sp, zin ? 0 : 1, r, zin, tau, frags, sgn, zout, patches, map_out, nullptr, 1,
-                               (precision >> 4) & 1, S(stream));
+                               (precision >> 4) & 1, li, lo, S(stream));
     }
     GParams p = {};
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
@@ -1058,10 +1088,11 @@ int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base
     if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
     if (strip) {
-        if ((precision >> 5) != 0) return CDL_EINVAL;
+        int li, lo;
+        if (!strip_layouts(precision, &li, &lo)) return CDL_EINVAL;
         if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
         return cdl_strip_stage(g, sp, 2, thin, base, nullptr, frags, 1.0f, du_out, patches, const_cast<unsigned *>(map),
-                               dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, S(stream));
+                               dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, li, lo, S(stream));
     }
     GParams p = {};
     p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
@@ -1125,10 +1156,16 @@ int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *m
     int rc = strip ? cdl_strip_prep_pairs(g, sp, wA, wB, K, 1, frags, S(stream))
                    : prep_pairs(g, pl, wA, wB, K, 1, frags, S(stream));     // (A_k, B_{k+1}) for every k
     if (rc) return rc;
+    // CDL_LAYOUT_IN(precision): the layout of z[0..K-2] (strip shapes: CDL_LAY_RSC allowed); z[K-1] is always the
+    // reference's (N,M,..) layout
+    const int lay = (precision >> 5) & 3, pbase = precision & 15;
+    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(strip && lay == CDL_LAY_RSC))) return CDL_EINVAL;
     for (int k = 0; k < K; ++k) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
+        const int flags = pbase | ((k & 1) && snake ? CDL_TILES_REVERSED : 0) | CDL_LAYOUT_IN(k ? lay : CDL_LAY_NCHW) |
+                          CDL_LAYOUT_OUT(k < K - 1 ? lay : CDL_LAY_NCHW);
         rc = cdl_fusedg_iter_fwd(g, thin, k ? z[k - 1] : nullptr, tau + k * nm, fk, k ? -1.0f : 1.0f, z[k], patches,
-                                 maps ? maps[k] : nullptr, precision | ((k & 1) && snake ? CDL_TILES_REVERSED : 0), stream);
+                                 maps ? maps[k] : nullptr, flags, stream);
         if (rc) return rc;
         if (k < K - 1) {
             rc = cdl_fusedg_assemble(g, patches, mask, yp, 1.0f, r[k], stream);
@@ -1161,6 +1198,12 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
     float *du[2] = {du0, du1};
     const int snake = cdl_opts().fused_snake;
     const int sdir = snake ? (((K - 1) & 1) ? CDL_TILES_REVERSED : 0) : 0;
+    // CDL_LAYOUT_IN(precision): the layout of z[0..K-2] and of the du buffers (strip shapes: CDL_LAY_RSC allowed, when
+    // the matrix-core filter-gradient kernel takes the geometry: its VALU fallbacks read the reference layout only)
+    const int lay = (precision >> 5) & 3;
+    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(strip && lay == CDL_LAY_RSC && cdl_mfma_wgrad_takes(g))))
+        return CDL_EINVAL;
+    const int rsc = lay == CDL_LAY_RSC;
     int rc = cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], wgrad_ws, wgrad_ws_floats, stream);      // dB_0 = z_K (x) dL/d(D z_K)
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
@@ -1172,17 +1215,21 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         float *duk = du[flip];
         rc = cdl_fusedg_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
-                                  (precision & 15) | (((K - 1 - k) & 1) ? (sdir ^ CDL_TILES_REVERSED) : sdir), stream);
+                                  (precision & 15) | (((K - 1 - k) & 1) ? (sdir ^ CDL_TILES_REVERSED) : sdir) |
+                                      CDL_LAYOUT_IN(k == K - 1 ? CDL_LAY_NCHW : lay) | CDL_LAYOUT_OUT(lay), stream);
         if (rc) return rc;
         rc = cdl_fusedg_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
         if (rc) return rc;
         if (k >= 1) {
             rc = cdl_fusedg_assemble(g, patches, mask, nullptr, -1.0f, q, stream);
             if (rc) return rc;
-            rc = cdl_wgrad_pair(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wgrad_ws_floats, stream);
+            rc = rsc ? cdl_mfma_wgrad_pair_lay(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws,
+                                               wgrad_ws_floats, 1, stream)
+                     : cdl_wgrad_pair(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws, wgrad_ws_floats, stream);
             thin = q;
         } else {
-            rc = cdl_wgrad(g, duk, nullptr, yp, 1.0f, dA[0], wgrad_ws, wgrad_ws_floats, stream);
+            rc = rsc ? cdl_mfma_wgrad_lay(g, duk, yp, 1.0f, dA[0], wgrad_ws, wgrad_ws_floats, 1, stream)
+                     : cdl_wgrad(g, duk, nullptr, yp, 1.0f, dA[0], wgrad_ws, wgrad_ws_floats, stream);
         }
         if (rc) return rc;
         base = duk;

@@ -21,6 +21,8 @@ int cdl_strip_prep_pairs(const cdl_geom *g, const cdl_strip_plan &pl, const floa
 // mode 0: z' = ST(zin + sgn * A r, tau), 1: the same without zin, 2: reverse stage (du = [map](zin + acc), dtau)
 int cdl_strip_stage(const cdl_geom *g, const cdl_strip_plan &pl, int mode, const float *r, const float *zin,
                     const float *tau, const void *frags, float sgn, float *zout, float *patches, unsigned *map,
-                    float *dtau_partial, int do_synth, int rev, hipStream_t st);
+                    float *dtau_partial, int do_synth, int rev, int lay_in, int lay_out, hipStream_t st);
+// floats of one code tensor in the row-strip channel-major layout (CDL_LAY_RSC): N * M * Hz * nsx * 32
+size_t cdl_strip_rsc_floats(const cdl_geom *g, const cdl_strip_plan &pl);
 int cdl_strip_assemble(const cdl_geom *g, const cdl_strip_plan &pl, const float *patches, const float *mask,
                        const float *sub, float alpha, float *out, hipStream_t st);

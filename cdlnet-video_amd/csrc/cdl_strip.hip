@@ -80,6 +80,7 @@ struct SParams {
     int do_synth;
     int N, M, H, W, Hz, Wz, MT, KQ, nsx, nsy, SEG, prows, rev;
     int items;
+    int lay_in, lay_out;     // 0: (N,M,Hz,Wz); 1: row-strip channel-major [n][yz][strip][M][32 px] (CDL_LAY_RSC)
     CDL_DBG_FIELD(int dbg;)  // probe build only (CDL_FUSED_DEBUG; results are wrong): 1 no fat loads, 2 no fat stores,
                              // 4 no analysis-like MFMAs, 8 no synthesis-like MFMAs, 16 no col2im, 32 no gather
 };
@@ -362,11 +363,27 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
             for (int gI = 0; gI <= NPRE; ++gI) thin_commit(gI - NPRE, tp[gI]);
         }
 
+        // fat addressing.  A (channel, code row, code column) element of sample n sits at
+        //   layout 0 (the reference's):  (ch * plane + yz * Wz + x) * 4
+        //   layout 1 (row-strip channel-major, inside a sweep):  ((yz * nsx + sx) * M + ch) * 128 + c * 4  -- the 32 columns
+        //     of a strip row are 128 contiguous bytes per channel and the channels follow each other, so everything a
+        //     wave moves for one code row (M * 128 B) is ONE contiguous run (whole DRAM pages, whole cache lines)
+        // per lane: channel half 4h and column; per element a scalar stride (estr); per step a scalar base.
+        const int bytes_in = p.lay_in ? M * p.Hz * p.nsx * 128 : M * plane4;
+        const int bytes_out = p.lay_out ? M * p.Hz * p.nsx * 128 : M * plane4;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-            has_base ? const_cast<float *>(p.zin) + (size_t)n * M * plane : p.zout, 0, has_base ? (int)(M * plane4) : 0, 0x00020000);
+            has_base ? const_cast<float *>(p.zin) + (size_t)n * (bytes_in / 4) : p.zout, 0, has_base ? bytes_in : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-            p.zout + (size_t)n * M * plane, 0, (int)(M * plane4), 0x00020000);
-        const int voff_x = xok ? (4 * h * plane + x) * 4 : OOB;
+            p.zout + (size_t)n * (bytes_out / 4), 0, bytes_out, 0x00020000);
+        const int estr_in = p.lay_in ? 128 : plane4, estr_out = p.lay_out ? 128 : plane4;
+        const int vlane_in = xok ? (p.lay_in ? (4 * h * 32 + c) * 4 : (4 * h * plane + x) * 4) : OOB;
+        const int vlane_out = xok ? (p.lay_out ? (4 * h * 32 + c) * 4 : (4 * h * plane + x) * 4) : OOB;
+        auto sbase_in = [&](int yz, int R) {
+            return __builtin_amdgcn_readfirstlane(p.lay_in ? ((yz * p.nsx + sx) * M + 32 * R) * 128 : (yz * p.Wz + 32 * R * plane) * 4);
+        };
+        auto sbase_out = [&](int yz, int R) {
+            return __builtin_amdgcn_readfirstlane(p.lay_out ? ((yz * p.nsx + sx) * M + 32 * R) * 128 : (yz * p.Wz + 32 * R * plane) * 4);
+        };
         unsigned *const map_n = p.map ? p.map + (size_t)n * (4 * MTP) * plane : nullptr;
 
         // The fat input of a channel tile is loaded INTO the accumulator registers of that tile: the matrix cores then
@@ -378,9 +395,12 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
         unsigned short supA = 0, supB = 0, supC = 0, sgnA = 0, sgnB = 0, sgnC = 0;         // reverse: the step's 16-bit halves of the map words
         // the register quad that straddles M (if any) addresses its missing channels out of range
         const int cb_part = (M & 7) ? (M & ~7) : -8;
-        int vo_part[4];
+        int vo_part_in[4], vo_part_out[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vo_part[e] = (cb_part + 4 * h + e < M) ? voff_x : OOB;
+        for (int e = 0; e < 4; ++e) {
+            vo_part_in[e] = (cb_part + 4 * h + e < M) ? vlane_in : OOB;
+            vo_part_out[e] = (cb_part + 4 * h + e < M) ? vlane_out : OOB;
+        }
         // element v of tile R = channel 32R + 8(v>>2) + 4h + (v&3); register quads beyond M stay zero (uniform skip)
         auto fat_issue = [&](int yz, int R, f32x16 &dst, unsigned short &sup, unsigned short &sgb) __attribute__((always_inline)) {
 #pragma unroll
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
                 }
             }
             if (MODE == MODE_FIRST || !has_base || CDL_DBG(p.dbg, 1)) return;
-            const int so0 = __builtin_amdgcn_readfirstlane((yz * p.Wz + 32 * R * plane) * 4);
+            const int so0 = sbase_in(yz, R);
 #pragma unroll
             for (int qv = 0; qv < 4; ++qv) {
                 const int cb = 32 * R + 8 * qv;
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     dst[4 * qv + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rs_in, cb == cb_part ? vo_part[e] : voff_x, so0 + (8 * qv + e) * plane4, 0));
+                        rs_in, cb == cb_part ? vo_part_in[e] : vlane_in, so0 + (8 * qv + e) * estr_in, 0));
             }
         };
 
@@ -436,7 +456,6 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
         // ---- one step: channel tile R of code row b, accumulators in `acc`
         auto step = [&](f32x16 &acc, unsigned short sup, unsigned short sgb) __attribute__((always_inline)) {
             const int yz = yz0 + b;
-            const int s_row = __builtin_amdgcn_readfirstlane(yz * p.Wz * 4);
             if (R == 0) {
                 // ---- im2col operand of this code row, gathered once for all channel tiles
                 const int s0 = (S * yz - HALO) & (RC - 1);
@@ -486,18 +505,18 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
             }
             // ---- epilogue
-            const int so0 = __builtin_amdgcn_readfirstlane(s_row + 32 * R * plane4);
+            const int so0 = sbase_out(yz, R);
             float tsum[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) tsum[v] = 0.0f;
             unsigned ws = 0, wg = 0;
             const bool nostore = CDL_DBG(p.dbg, 2);
             if (tau_neg)                                                 // wave-uniform
-                strip_epilogue<MODE, MAPPED, true>(acc, tsum, ws, wg, tau_s, R, M, h, cb_part, vo_part, voff_x, rs_out, so0,
-                                                   plane4, sup, sgb, nostore);
+                strip_epilogue<MODE, MAPPED, true>(acc, tsum, ws, wg, tau_s, R, M, h, cb_part, vo_part_out, vlane_out, rs_out, so0,
+                                                   estr_out, sup, sgb, nostore);
             else
-                strip_epilogue<MODE, MAPPED, false>(acc, tsum, ws, wg, tau_s, R, M, h, cb_part, vo_part, voff_x, rs_out, so0,
-                                                    plane4, sup, sgb, nostore);
+                strip_epilogue<MODE, MAPPED, false>(acc, tsum, ws, wg, tau_s, R, M, h, cb_part, vo_part_out, vlane_out, rs_out, so0,
+                                                    estr_out, sup, sgb, nostore);
             if (MODE != MODE_BWD && MAPPED && xok) {
                 // this tile's 16-bit half of the pair's map words (a sign bit only where there is support)
                 unsigned *mw = map_n + (size_t)((2 * (R >> 1) + h) * 2) * plane + (size_t)yz * p.Wz + x;
@@ -772,7 +791,7 @@ int cdl_strip_prep_pairs(const cdl_geom *g, const cdl_strip_plan &pl, const floa
 
 int cdl_strip_stage(const cdl_geom *g, const cdl_strip_plan &pl, int mode, const float *r, const float *zin,
                     const float *tau, const void *frags, float sgn, float *zout, float *patches, unsigned *map,
-                    float *dtau_partial, int do_synth, int rev, hipStream_t st)
+                    float *dtau_partial, int do_synth, int rev, int lay_in, int lay_out, hipStream_t st)
 {
     if (sgn != 1.0f && sgn != -1.0f) return CDL_EINVAL;              // the accumulator carries sgn * zin: |sgn| = 1 only
     SParams p = {};
@@ -781,10 +800,17 @@ int cdl_strip_stage(const cdl_geom *g, const cdl_strip_plan &pl, int mode, const
     p.patches = patches; p.sgn = sgn; p.do_synth = do_synth;
     p.N = g->N; p.M = g->M; p.H = g->H; p.W = g->W; p.Hz = pl.Hz; p.Wz = pl.Wz; p.MT = pl.MT; p.KQ = pl.KQ;
     p.nsx = pl.nsx; p.nsy = pl.nsy; p.SEG = pl.SEG; p.prows = pl.prows; p.rev = rev; p.items = (int)pl.items;
+    p.lay_in = lay_in; p.lay_out = lay_out;
+    if ((size_t)g->M * pl.Hz * pl.nsx * 128 >= ((size_t)1 << 31)) return CDL_EUNSUPPORTED;
     CDL_DBG_FIELD(p.dbg = cdl_opts().fused_debug;)
     if (pl.P == 3) return launch_s<3>(p, pl, mode, st);
     if (pl.P == 5) return launch_s<5>(p, pl, mode, st);
     return launch_s<7>(p, pl, mode, st);
+}
+
+size_t cdl_strip_rsc_floats(const cdl_geom *g, const cdl_strip_plan &pl)
+{
+    return (size_t)g->N * g->M * pl.Hz * pl.nsx * 32;
 }
 
 int cdl_strip_assemble(const cdl_geom *g, const cdl_strip_plan &pl, const float *patches, const float *mask,

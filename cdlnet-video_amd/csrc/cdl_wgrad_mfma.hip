@@ -58,7 +58,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                                              const float *__restrict__ gate, const float *__restrict__ x0,
                                              float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP CDL_DBG_COMMA(int dbg),
                                              int ntiles, int tpw, const float *__restrict__ F1,
-                                             const float *__restrict__ x1)
+                                             const float *__restrict__ x1, int rsc)
 {
     // blockIdx.y = 1: the second (fat, thin) operand pair of a paired launch (dA_k and dB_k of one iteration), its
     // partial banks behind the first pair's
@@ -87,6 +87,14 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
     const bool active = pp < npx;                          // 8 % nct waves idle when nct does not divide 8
     const int kpw = KSTEPS / npx;                          // k-steps per wave
     const size_t slab = (size_t)Dz * Hz * Wz;
+    // rsc != 0 (2-D only): the fat operands are in the strip kernel's row-strip channel-major layout
+    // [n][code row][ceil(Wz/32)][M][32 columns] (include/cdlnet_hip.h, CDL_LAY_RSC): a lane's 8 consecutive pixels are
+    // still 32 contiguous bytes (they never straddle a 32-column strip), the 32 channels of a half-wave are 128 bytes apart
+    const int nsx = (Wz + 31) >> 5;
+    auto fat_index = [&](int m, int cy, int cx) -> size_t {
+        return rsc ? (((size_t)n * Hz + cy) * nsx + (cx >> 5)) * ((size_t)g.M * 32) + (size_t)m * 32 + (cx & 31)
+                   : fbase + (size_t)m * slab + (size_t)cy * Wz + cx;
+    };
     // 16-byte loads of the fat operand need rows that start on 16-byte boundaries (the base pointers do)
     const bool vec4 = (Wz & 3) == 0 && ((reinterpret_cast<size_t>(F) | reinterpret_cast<size_t>(gate)) & 15) == 0;
 
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
             for (int q = 0; q < CT; ++q) {
                 const int m = 32 * (CT * cg + q) + l32;
                 const bool ok = m < g.M && cy < Hz && cx0 < Wz;
-                const size_t idx = ok ? fbase + (size_t)m * slab + (size_t)cy * Wz + cx0 : fbase;
+                const size_t idx = ok ? fat_index(m, cy, cx0) : fat_index(0, 0, 0);
                 fr[q][0] = *reinterpret_cast<const f32x4 *>(F + idx);
                 fr[q][1] = *reinterpret_cast<const f32x4 *>(F + idx + 4);
             }
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 for (int q = 0; q < CT; ++q) {
                     const int m = 32 * (CT * cg + q) + l32;
                     const bool mok = m < g.M && cy < Hz;
-                    const size_t rowi = fbase + (size_t)(mok ? m : 0) * slab + (size_t)(mok ? cy : 0) * Wz;
+                    // (index of pixel cx0 of this lane's row; the 8 pixels of a k-step follow contiguously in both layouts)
+                    const size_t rowi = fat_index(mok ? m : 0, mok ? cy : 0, cx0 < Wz ? cx0 : 0) - (cx0 < Wz ? cx0 : 0);
                     float fv[8];
                     if (vec4 && mok && cx0 + 8 <= Wz) {            // whole 32-byte segment inside the row: two 16-byte loads
                         const float4 a0 = *reinterpret_cast<const float4 *>(F + rowi + cx0);
@@ -499,34 +508,33 @@ bool plan_for(const cdl_geom *g, Plan *p)
 
 template <int PH, int PW, int SW, int NG, int CT>
 int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
-              hipStream_t st, const float *F1, const float *x1)
+              hipStream_t st, const float *F1, const float *x1, int rsc)
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
     k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1), GNT, p.lds, st>>>(
         *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP CDL_DBG_COMMA(cdl_opts().fused_debug & (1024 | 2048 | 4096)), (int)p.tiles,
-        p.tpw, F1, x1);
+        p.tpw, F1, x1, rsc);
     CDL_LAUNCH_CHECK();
     return 0;
 }
 
 template <int PH, int PW, int SW, int NG>
 int launch_ng(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float *ws,
-              hipStream_t st, const float *F1, const float *x1)
+              hipStream_t st, const float *F1, const float *x1, int rsc)
 {
-    return p.ct == 1 ? launch_ct<PH, PW, SW, NG, 1>(g, p, F, gate, x, ws, st, F1, x1)
-                     : launch_ct<PH, PW, SW, NG, 2>(g, p, F, gate, x, ws, st, F1, x1);
+    return p.ct == 1 ? launch_ct<PH, PW, SW, NG, 1>(g, p, F, gate, x, ws, st, F1, x1, rsc)
+                     : launch_ct<PH, PW, SW, NG, 2>(g, p, F, gate, x, ws, st, F1, x1, rsc);
 }
 
 template <int PH, int PW, int SW>
 int launch(const cdl_geom *g, const Plan &p, const float *F, const float *gate, const float *x, float alpha,
-           float *dw, float *ws, hipStream_t st, const float *F1 = nullptr, const float *x1 = nullptr,
-           float alpha1 = 0.0f, float *dw1 = nullptr)
+           float *dw, float *ws, hipStream_t st, const float *F1, const float *x1, float alpha1, float *dw1, int rsc)
 {
     constexpr int RT = (PH * PW + 31) / 32;
     int rc;
-    if (RT == 1 && p.ng == 5) rc = launch_ng<PH, PW, SW, (RT == 1 ? 5 : 1)>(g, p, F, gate, x, ws, st, F1, x1);
-    else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st, F1, x1);
-    else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st, F1, x1);
+    if (RT == 1 && p.ng == 5) rc = launch_ng<PH, PW, SW, (RT == 1 ? 5 : 1)>(g, p, F, gate, x, ws, st, F1, x1, rsc);
+    else if (RT <= 2 && p.ng == 3) rc = launch_ng<PH, PW, SW, (RT <= 2 ? 3 : 1)>(g, p, F, gate, x, ws, st, F1, x1, rsc);
+    else rc = launch_ng<PH, PW, SW, 1>(g, p, F, gate, x, ws, st, F1, x1, rsc);
     if (rc) return rc;
     const int G = g->C * g->Pd, T = g->Ph * g->Pw;
     k_wgm_fold<<<dim3(G * T * ((g->M + 15) / 16), F1 ? 2 : 1), 256, 0, st>>>(ws, dw, alpha, (int)p.blocks, G, g->M, T,
@@ -546,17 +554,18 @@ size_t cdl_mfma_wgrad_ws_floats(const cdl_geom *g)
 // CDL_EUNSUPPORTED: the caller falls back to the VALU kernels
 static int wgrad_entry(const cdl_geom *g, const float *F, const float *gate, const float *x, float alpha, float *dw,
                        const float *F1, const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats,
-                       void *stream)
+                       void *stream, int rsc = 0)
 {
     Plan p;
     if (!plan_for(g, &p) || !ws) return CDL_EUNSUPPORTED;
+    if (rsc && (gate || g->D != 1 || g->sd != 1)) return CDL_EUNSUPPORTED;
     const size_t jobs = F1 ? 2 : 1;
     const size_t cus = (size_t)cdl_cu_count();              // one workgroup per CU at a time (registers): tiles per
     p.tpw = (int)((jobs * p.tiles + cus - 1) / cus);        // workgroup = the number of rounds a tile-per-workgroup grid takes
     p.blocks = (p.tiles + p.tpw - 1) / p.tpw;
     if (ws_floats < jobs * p.blocks * ((size_t)g->C * g->Pd * p.TP * p.MP)) return CDL_EUNSUPPORTED;
 #define CDL_M(P_, S_) \
-    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream), F1, x1, alpha1, dw1)
+    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream), F1, x1, alpha1, dw1, rsc)
     CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
     CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
 #undef CDL_M
@@ -574,4 +583,26 @@ int cdl_mfma_wgrad_pair(const cdl_geom *g, const float *F0, const float *x0, flo
                         const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats, void *stream)
 {
     return wgrad_entry(g, F0, nullptr, x0, alpha0, dw0, F1, x1, alpha1, dw1, ws, ws_floats, stream);
+}
+
+// The same with the fat operands in the strip kernel's row-strip channel-major layout (cdl_strip.hip; rsc != 0), for the
+// reverse sweep of the strip shapes.  cdl_mfma_wgrad_takes: this kernel (and not a VALU fallback, which reads the
+// reference layout only) is what cdl_wgrad would run for the geometry.
+bool cdl_mfma_wgrad_takes(const cdl_geom *g)
+{
+    Plan p;
+    return cdl_opts().mfma_wgrad && plan_for(g, &p);
+}
+
+int cdl_mfma_wgrad_lay(const cdl_geom *g, const float *F, const float *x, float alpha, float *dw, float *ws,
+                       size_t ws_floats, int rsc, void *stream)
+{
+    return wgrad_entry(g, F, nullptr, x, alpha, dw, nullptr, nullptr, 0.0f, nullptr, ws, ws_floats, stream, rsc);
+}
+
+int cdl_mfma_wgrad_pair_lay(const cdl_geom *g, const float *F0, const float *x0, float alpha0, float *dw0,
+                            const float *F1, const float *x1, float alpha1, float *dw1, float *ws, size_t ws_floats,
+                            int rsc, void *stream)
+{
+    return wgrad_entry(g, F0, nullptr, x0, alpha0, dw0, F1, x1, alpha1, dw1, ws, ws_floats, stream, rsc);
 }

@@ -134,21 +134,22 @@ def _forward_fused_stepwise(g, yp, mask_p, tau, A, B, keep_codes, keep_resid, la
     return xp, z, codes, resid, maps
 
 
-def _forward_fusedg(g, yp, mask_p, tau, A, B, keep_codes, keep_resid):
-    """cdl_fusedg_forward: the fused iteration for C > 1 / 3-D / P in {3,5,7} / M <= 64 (one fused launch + a thin
-    assemble per iteration)."""
+def _forward_fusedg(g, yp, mask_p, tau, A, B, keep_codes, keep_resid, layout="nchw"):
+    """cdl_fusedg_forward: the fused iteration for C > 1 / 3-D / P in {3,5,7} / M <= 64, and (the strip kernel) for one
+    image channel, stride 1 / 2, M <= 192: one fused launch + a thin assemble per iteration.  codes[:-1] come back in
+    `layout` ("nchw", or "rsc" where ops.fusedg_code_layout(g) says so), codes[-1] = z_K as (N,M,..)."""
     keep = keep_codes or keep_resid
-    xp, z, codes, resid, maps = ops.fusedg_forward(g, yp, mask_p, tau, A, B, keep)
+    xp, z, codes, resid, maps = ops.fusedg_forward(g, yp, mask_p, tau, A, B, keep, layout)
     return xp, z, codes, (resid if keep_resid else []), (maps if keep_resid else [])
 
 
-def _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
+def _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout="nchw"):
     """cdl_fusedg_backward: per iteration one fused reverse stage (du_k, threshold partials, patches of q_k), a thin
-    assemble and the two filter gradients."""
+    assemble and the two filter gradients.  `layout`: that of codes[:-1]."""
     if g_xp is None and g_z is None:
         return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
     return ops.fusedg_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
-                               maps=list(maps) if maps else None)
+                               maps=list(maps) if maps else None, layout=layout)
 
 
 def _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
@@ -249,7 +250,9 @@ class UnrolledISTA(torch.autograd.Function):
         ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
         ctx.fusedg = BACKEND == "auto" and not ctx.fused and ops.fusedg_supported(g)
         if ctx.fusedg:
-            xp, z, codes, resid, maps = _forward_fusedg(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
+            # codes handed to the caller (forward_generator) must be (N,M,..); otherwise they stay in the sweeps' layout
+            ctx.layout = "nchw" if want_codes else ops.fusedg_code_layout(g)
+            xp, z, codes, resid, maps = _forward_fusedg(g, yp, mask_p, tau, A, B, keep or want_codes, keep, ctx.layout)
         elif ctx.fused:
             # codes handed to the caller (forward_generator) must be (N,M,H,W); otherwise they stay internal
             ctx.layout = "nchw" if want_codes else CODE_LAYOUT
@@ -290,7 +293,7 @@ class UnrolledISTA(torch.autograd.Function):
         if g_z is not None:
             g_z = g_z.contiguous()
         if ctx.fusedg:
-            dA, dB = _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
+            dA, dB = _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps, layout=ctx.layout)
         elif ctx.fused:                                # a loss on z only is a zero image gradient to the sweep
             dA, dB = _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps,
                                      layout=ctx.layout)

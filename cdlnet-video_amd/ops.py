@@ -524,7 +524,7 @@ PRECISION = {"split3": 0, "bf16": 1}
 # layouts of the fat tensors that stay inside a fused sweep (include/cdlnet_hip.h, CDL_LAY_*): "nchw" is the
 # reference's layout, "blocked" the pixel-blocked fp32 layout (same values, 16-byte accesses, the default),
 # "blocked_bf16" opt-in bf16 STORAGE of the codes (half the bytes; outside the 1e-5 parity gate)
-LAYOUT = {"nchw": 0, "blocked": 1, "blocked_bf16": 2}
+LAYOUT = {"nchw": 0, "blocked": 1, "blocked_bf16": 2, "rsc": 3}
 TILES_REVERSED = 16
 
 
@@ -824,14 +824,40 @@ def fusedg_patches(g: Geometry, device):
     return torch.empty(_fusedg_sizes(g)[1], device=device, dtype=torch.float32)
 
 
-def fusedg_iter(g: Geometry, r, zin, tau, frags, sgn, patches, out=None, map_out=None):
+def fusedg_rsc_buffer(g: Geometry, device, count=1):
+    """Flat fp32 buffer(s) for code tensors in the strip kernel's row-strip channel-major layout ("rsc":
+    [n][code row][ceil(Wz/32)][M][32 columns]; include/cdlnet_hip.h CDL_LAY_RSC)."""
+    hz, wz = g.code_shape()[-2:]
+    n = g.N * g.M * hz * ((wz + 31) // 32) * 32
+    return torch.empty((count, n), device=device, dtype=torch.float32)
+
+
+def fusedg_to_rsc(g: Geometry, z):
+    """(N,M,Hz,Wz) -> flat rsc buffer (host-side plumbing for tests)."""
+    N, M, hz, wz = g.code_shape()
+    nsx = (wz + 31) // 32
+    zp = torch.zeros((N, M, hz, nsx * 32), device=z.device, dtype=torch.float32)
+    zp[..., :wz] = z.reshape(N, M, hz, wz)
+    return zp.reshape(N, M, hz, nsx, 32).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def fusedg_from_rsc(g: Geometry, buf):
+    N, M, hz, wz = g.code_shape()
+    nsx = (wz + 31) // 32
+    z = buf.reshape(N, hz, nsx, M, 32).permute(0, 3, 1, 2, 4).reshape(N, M, hz, nsx * 32)
+    return z[..., :wz].contiguous()
+
+
+def fusedg_iter(g: Geometry, r, zin, tau, frags, sgn, patches, out=None, map_out=None, lay_in="nchw", lay_out="nchw"):
     r, zin, tau = _dev(r, "r"), _opt(zin, "zin"), _dev(tau, "tau")
     assert tuple(r.shape) == g.image_shape()
     if out is None:
-        out = torch.empty(g.code_shape(), device=r.device, dtype=torch.float32)
+        out = (torch.empty(g.code_shape(), device=r.device, dtype=torch.float32) if lay_out == "nchw"
+               else fusedg_rsc_buffer(g, r.device)[0])
     gs = g.c_struct()
     rc = _lib.lib().cdl_fusedg_iter_fwd(ctypes.byref(gs), _ptr(r), _ptr(zin), _ptr(tau), _ptr(frags), float(sgn),
-                                        _ptr(out), _ptr(patches), _ptr(map_out), 0, _stream())
+                                        _ptr(out), _ptr(patches), _ptr(map_out), _lay_in(lay_in) | _lay_out(lay_out),
+                                        _stream())
     _lib.check(rc, "cdl_fusedg_iter_fwd")
     return out
 
@@ -871,14 +897,17 @@ def fusedg_support_map(g: Geometry, z):
     return out.to(torch.int32).contiguous()
 
 
-def fusedg_stage_bwd(g: Geometry, thin, base, gate_map, frags, patches, dtau_partial, do_synth, out=None):
+def fusedg_stage_bwd(g: Geometry, thin, base, gate_map, frags, patches, dtau_partial, do_synth, out=None,
+                     lay_in="nchw", lay_out="nchw"):
     thin, base = _dev(thin, "thin"), _opt(base, "base")
     assert gate_map.dtype == torch.int32 and gate_map.is_contiguous()
     if out is None:
-        out = torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32)
+        out = (torch.empty(g.code_shape(), device=thin.device, dtype=torch.float32) if lay_out == "nchw"
+               else fusedg_rsc_buffer(g, thin.device)[0])
     gs = g.c_struct()
     rc = _lib.lib().cdl_fusedg_stage_bwd(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate_map), _ptr(frags),
-                                         _ptr(out), _ptr(patches), _ptr(dtau_partial), int(bool(do_synth)), 0, _stream())
+                                         _ptr(out), _ptr(patches), _ptr(dtau_partial), int(bool(do_synth)),
+                                         _lay_in(lay_in) | _lay_out(lay_out), _stream())
     _lib.check(rc, "cdl_fusedg_stage_bwd")
     return out
 
@@ -892,19 +921,35 @@ def fusedg_dtau_reduce(g: Geometry, dtau_partial, c, dt_k):
     _lib.check(rc, "cdl_fusedg_dtau_reduce")
 
 
-def fusedg_forward(g: Geometry, yp, mask_p, tau, A, B, keep):
-    """Whole forward sweep in one C call (cdl_fusedg_forward); same contract as fused_forward, NCHW codes."""
+def fusedg_code_layout(g: Geometry) -> str:
+    """Layout the fused generic sweeps keep their internal codes in: "rsc" for the strip kernel's shapes when the
+    matrix-core filter-gradient kernel takes the geometry, else "nchw" (cdl_fusedg_code_layout)."""
+    gs = g.c_struct()
+    return "rsc" if int(_lib.lib().cdl_fusedg_code_layout(ctypes.byref(gs))) == LAYOUT["rsc"] else "nchw"
+
+
+def _fusedg_code_buffers(g: Geometry, layout, device, count):
+    """`count` code tensors of a sweep: (N,M,..) tensors for "nchw", flat buffers for "rsc"."""
+    if layout == "nchw":
+        return list(torch.empty((max(count, 1),) + g.code_shape(), device=device, dtype=torch.float32).unbind(0))
+    return list(fusedg_rsc_buffer(g, device, max(count, 1)).unbind(0))
+
+
+def fusedg_forward(g: Geometry, yp, mask_p, tau, A, B, keep, layout="nchw"):
+    """Whole forward sweep in one C call (cdl_fusedg_forward); same contract as fused_forward: codes[:-1] come back
+    in `layout` ("nchw", or "rsc" where fusedg_code_layout allows it), codes[-1] = z_K as (N,M,..)."""
     K = len(A)
     yp, tau, mask_p = _dev(yp, "yp"), _dev(tau, "tau"), _opt(mask_p, "mask")
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
     dev = yp.device
     fb, pf, tiles, mw = _fusedg_sizes(g)
-    nz = K if keep else min(K, 2)
+    nz = (K - 1) if keep else min(K - 1, 2)                 # internal codes z_1..z_{K-1}; z_K has its own tensor
     nr = (K - 1) if keep else min(K - 1, 2)
-    zbuf = torch.empty((nz,) + g.code_shape(), device=dev, dtype=torch.float32)
+    zint = _fusedg_code_buffers(g, layout, dev, nz)
+    zK = torch.empty(g.code_shape(), device=dev, dtype=torch.float32)
     rbuf = torch.empty((max(nr, 1),) + g.image_shape(), device=dev, dtype=torch.float32)
-    z = [zbuf[k % nz] for k in range(K)]
+    z = [zint[k % nz] for k in range(K - 1)] + [zK]
     r = [rbuf[k % nr] for k in range(K - 1)] if K > 1 else []
     maps = list(torch.empty((K,) + _fusedg_map_shape(g), device=dev, dtype=torch.int32).unbind(0)) if keep else []
     xp = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
@@ -914,17 +959,19 @@ def fusedg_forward(g: Geometry, yp, mask_p, tau, A, B, keep):
     rc = _lib.lib().cdl_fusedg_forward(ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(tau), _ptr_table(A),
                                        _ptr_table(B), _ptr_table(z), _ptr_table(r) if r else None,
                                        _ptr_table(maps) if maps else None, _ptr(xp), _ptr(frags), _ptr(patches),
-                                       0, _stream())
+                                       _lay_in(layout), _stream())
     _lib.check(rc, "cdl_fusedg_forward")
-    return xp, z[K - 1], (z if keep else [z[K - 1]]), (r if keep else []), maps
+    return xp, zK, (z if keep else [zK]), (r if keep else []), maps
 
 
-def fusedg_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None):
-    """Whole reverse sweep in one C call (cdl_fusedg_backward); returns (dA list, dB list), fills dt (K,2,M)."""
+def fusedg_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout="nchw"):
+    """Whole reverse sweep in one C call (cdl_fusedg_backward); returns (dA list, dB list), fills dt (K,2,M).
+    `layout`: that of codes[:-1] (and of the du buffers allocated here)."""
     K = len(A)
     dev = yp.device
     if not maps:
-        maps = [fusedg_support_map(g, t) for t in codes]
+        nchw = [t if (layout == "nchw" or i == K - 1) else fusedg_from_rsc(g, t) for i, t in enumerate(codes)]
+        maps = [fusedg_support_map(g, t) for t in nchw]
     A = [_dev(w, "A") for w in A]
     B = [_dev(w, "B") for w in B]
     codes = [_dev(t, "z") for t in codes]
@@ -935,7 +982,7 @@ def fusedg_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, d
     fb, pf, tiles, mw = _fusedg_sizes(g)
     dAB = torch.empty((2 * K,) + g.filter_shape(), device=dev, dtype=torch.float32)
     dA, dB = list(dAB[:K].unbind(0)), list(dAB[K:].unbind(0))
-    du = torch.empty((2 if K > 1 else 1,) + g.code_shape(), device=dev, dtype=torch.float32)
+    du = _fusedg_code_buffers(g, layout, dev, 2 if K > 1 else 1)
     q = torch.empty(g.image_shape(), device=dev, dtype=torch.float32)
     frags = torch.empty(K * fb, device=dev, dtype=torch.uint8)
     patches = torch.empty(pf, device=dev, dtype=torch.float32)
@@ -948,7 +995,7 @@ def fusedg_backward(g: Geometry, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, d
         ctypes.byref(gs), K, _ptr(yp), _ptr(mask_p), _ptr(c), _ptr_table(A), _ptr_table(B), _ptr_table(codes),
         _ptr_table(resid) if resid else None, _ptr_table(list(maps)), _ptr(g_xp), _ptr(g_z), _ptr_table(dA),
         _ptr_table(dB), _ptr(dt), _ptr(du[0]), _ptr(du[1 if K > 1 else 0]), _ptr(q), _ptr(frags), _ptr(patches),
-        _ptr(dtp), _ptr(ws), nws, 0, _stream())
+        _ptr(dtp), _ptr(ws), nws, _lay_in(layout), _stream())
     _lib.check(rc, "cdl_fusedg_backward")
     return dA, dB
 

@@ -291,6 +291,10 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
 #define CDL_LAY_NCHW  0
 #define CDL_LAY_BLK   1
 #define CDL_LAY_BLK16 2
+/* cdl_fusedg_* on the strip kernel's shapes (one image channel, stride 1 / 2, M <= 192) only: row-strip channel-major
+ * fp32 [n][code row][ceil(Wz/32)][M][32 columns] -- what a wave moves per code row is one contiguous run of M * 128
+ * bytes.  Same values as CDL_LAY_NCHW; for the codes that stay inside a sweep. */
+#define CDL_LAY_RSC   3
 #define CDL_LAYOUT_IN(l)  ((l) << 5)
 #define CDL_LAYOUT_OUT(l) ((l) << 7)
 
@@ -385,6 +389,12 @@ size_t cdl_fusedg_frag_bytes(const cdl_geom *g);           /* bytes of one prepa
 size_t cdl_fusedg_patch_floats(const cdl_geom *g);
 size_t cdl_fusedg_tiles(const cdl_geom *g);                /* workgroup tiles (= dtau_partial rows) per launch */
 size_t cdl_fusedg_map_words(const cdl_geom *g);
+/* Layout for the codes that stay inside a sweep (z[0..K-2], the du buffers): CDL_LAY_RSC where the strip kernel and the
+ * matrix-core filter-gradient kernel both take the geometry, CDL_LAY_NCHW otherwise; floats of one code tensor in a
+ * layout.  cdl_fusedg_forward / _backward take it as CDL_LAYOUT_IN(layout) in `precision`; the single-stage entry points
+ * take CDL_LAYOUT_IN (zin / base) and CDL_LAYOUT_OUT (zout / du_out). */
+int cdl_fusedg_code_layout(const cdl_geom *g);
+size_t cdl_fusedg_code_floats(const cdl_geom *g, int layout);
 int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream);
 int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/, const float *tau /*N,M*/,
                         const void *frags, float sgn, float *zout, float *patches, unsigned *map_out /*nullable*/,

@@ -126,6 +126,8 @@ def test_strip_backward_stage_vs_generic(N, M, P, s, sp, masked):
     (dict(K=4, M=169, P=7, s=2, C=1), (2, 1, 75, 77), False),      # odd size: stride padding in pre_process
     (dict(K=3, M=64, P=5, s=2, C=1), (1, 1, 40, 72), True),
     (dict(K=3, M=100, P=7, s=1, C=1), (1, 1, 33, 70), False),
+    (dict(K=3, M=169, P=7, s=2, C=1), (16, 1, 128, 250), True),    # enough filter-gradient tiles: internal codes in "rsc"
+    (dict(K=3, M=72, P=5, s=1, C=1), (12, 1, 96, 100), False),     # "rsc" at unit stride, ragged last strip
 ])
 def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked):
     """Forward: strip sweep vs generic sweep; reverse: both sweeps fed the SAME saved activations (no support flip can
@@ -155,20 +157,29 @@ def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked):
     tau = o.thresholds(net.t.detach(), c, N)
     A = [m.weight.detach() for m in net.A]
     B = [m.weight.detach() for m in net.B]
-    xp, z, codes, resid, maps = loop._forward_fusedg(g, yp, mask_p, tau, A, B, True, True)
+    lay = o.fusedg_code_layout(g)                      # "rsc" when the matrix-core filter-gradient kernel takes the shape
+    assert lay == ("rsc" if shape[0] >= 10 else "nchw")
+    xp, z, codes, resid, maps = loop._forward_fusedg(g, yp, mask_p, tau, A, B, True, True, lay)
     xpg, zg, codes_g, resid_g, _ = loop._forward_generic(g, yp, mask_p, tau, A, B, True, True)
-    tag = f"strip sweep K{K} M{M} P{P} s{s} {shape}"
+    tag = f"strip sweep[{lay}] K{K} M{M} P{P} s{s} {shape}"
     check(f"{tag} xp", xp, xpg, 1e-5)
     check(f"{tag} z_K", z, zg, 5e-5)
-    assert all(torch.equal(m, o.fusedg_support_map(g, zc)) for m, zc in zip(maps, codes))
-    xp2, z2, _, _, _ = loop._forward_fusedg(g, yp, mask_p, tau, A, B, False, False)          # ping-pong buffers
+    codes_n = [zc if (lay == "nchw" or i == K - 1) else o.fusedg_from_rsc(g, zc) for i, zc in enumerate(codes)]
+    assert all(torch.equal(m, o.fusedg_support_map(g, zc)) for m, zc in zip(maps, codes_n))
+    xp2, z2, _, _, _ = loop._forward_fusedg(g, yp, mask_p, tau, A, B, False, False, lay)     # ping-pong buffers
     assert torch.equal(xp2, xp) and torch.equal(z2, z)
+    if lay != "nchw":                                   # the layout changes no value
+        xp3, z3, codes3, _, _ = loop._forward_fusedg(g, yp, mask_p, tau, A, B, True, True, "nchw")
+        assert torch.equal(xp3, xp) and torch.equal(z3, z) and all(torch.equal(a, b) for a, b in zip(codes3, codes_n))
     g_xp = torch.randn(xp.shape, generator=torch.Generator().manual_seed(8)).cuda()
     g_z = torch.randn(z.shape, generator=torch.Generator().manual_seed(9)).cuda() * 0.01
     outs = {}
     for name, sweep in (("strip", loop._backward_fusedg), ("generic", loop._backward_generic), ("again", loop._backward_fusedg)):
         dt = torch.zeros(K, 2, M, device="cuda")
-        dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps)
+        if name == "generic":
+            dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes_n, resid, g_xp, g_z, dt, maps=maps)
+        else:
+            dA, dB = sweep(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps, layout=lay)
         outs[name] = (dA, dB, dt)
     for k in range(K):
         check(f"{tag} dA[{k}]", outs["strip"][0][k], outs["generic"][0][k], 5e-5)
@@ -178,8 +189,40 @@ def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked):
     assert torch.equal(outs["strip"][2], outs["again"][2])
     # the reverse sweep without the forward's maps rebuilds them from the codes: same result
     dt = torch.zeros(K, 2, M, device="cuda")
-    dA, dB = loop._backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None)
+    dA, dB = loop._backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout=lay)
     assert all(torch.equal(a, b) for a, b in zip(dA, outs["strip"][0])) and torch.equal(dt, outs["strip"][2])
+
+
+@pytest.mark.parametrize("N,M,P,s,sp", [(2, 169, 7, 2, (64, 128)), (1, 100, 7, 1, (33, 70)), (1, 169, 7, 2, (150, 154))])
+def test_strip_rsc_layout_is_bit_identical_to_the_reference_layout(N, M, P, s, sp):
+    """CDL_LAY_RSC (row-strip channel-major, what the sweeps keep their internal codes in) against the reference's
+    (N,M,Hz,Wz): same values bit for bit, on either side of the forward and of the reverse stage."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    gen = torch.Generator().manual_seed(17 + M)
+    g = make_geom(N, M, P, s, sp)
+    r = torch.randn(g.image_shape(), generator=gen).cuda()
+    z = (torch.randn(g.code_shape(), generator=gen) * (torch.rand(g.code_shape(), generator=gen) < 0.3)).cuda()
+    w = (torch.randn(g.filter_shape(), generator=gen) * 0.1).cuda()
+    tau = (torch.rand(N, M, generator=gen) * 0.6 + 0.01).cuda()
+    frags, patches = o.fusedg_prep(g, w, w), o.fusedg_patches(g, "cuda")
+    assert torch.equal(o.fusedg_from_rsc(g, o.fusedg_to_rsc(g, z)), z)
+    ref = o.fusedg_iter(g, r, z, tau, frags, -1.0, patches)
+    r_ref = o.fusedg_assemble(g, patches)
+    zr = o.fusedg_to_rsc(g, z)
+    for li, lo in (("rsc", "rsc"), ("rsc", "nchw"), ("nchw", "rsc")):
+        out = o.fusedg_iter(g, r, zr if li == "rsc" else z, tau, frags, -1.0, patches, lay_in=li, lay_out=lo)
+        assert torch.equal(out if lo == "nchw" else o.fusedg_from_rsc(g, out), ref), (li, lo)
+        assert torch.equal(o.fusedg_assemble(g, patches), r_ref)
+    bits = o.fusedg_support_map(g, z)
+    dtp = torch.empty(o._fusedg_sizes(g)[2], M, device="cuda")
+    base = torch.randn(g.code_shape(), generator=gen).cuda()
+    du_ref = o.fusedg_stage_bwd(g, r, base, bits, frags, patches, dtp, True)
+    dtp_ref = dtp.clone()
+    for li, lo in (("rsc", "rsc"), ("nchw", "rsc")):
+        du = o.fusedg_stage_bwd(g, r, o.fusedg_to_rsc(g, base) if li == "rsc" else base, bits, frags, patches, dtp, True,
+                                lay_in=li, lay_out=lo)
+        assert torch.equal(o.fusedg_from_rsc(g, du), du_ref) and torch.equal(dtp, dtp_ref), (li, lo)
 
 
 def test_s2030_net_routes_through_the_strip_kernel_and_is_sample_independent():

@@ -69,7 +69,15 @@ def launch_times():
     dtp = torch.empty(o._fusedg_sizes(g)[2], M, device="cuda")
     thin = torch.empty_like(r)
     fat = z.numel() * 4
+    zr, outr = o.fusedg_to_rsc(g, z), o.fusedg_rsc_buffer(g, "cuda")[0]
+    chk = o.fusedg_from_rsc(g, o.fusedg_iter(g, r, zr, tau, frags, -1.0, patches, out=outr, lay_in="rsc", lay_out="rsc"))
+    ref = o.fusedg_iter(g, r, z, tau, frags, -1.0, patches)
+    print("rsc == nchw bit for bit:", bool(torch.equal(chk, ref)), flush=True)
     for name, fn, nbytes in (
+            ("strip FWD rsc->rsc", lambda: o.fusedg_iter(g, r, zr, tau, frags, -1.0, patches, out=outr, lay_in="rsc", lay_out="rsc"), 2 * fat),
+            ("strip FWD rsc->rsc + map", lambda: o.fusedg_iter(g, r, zr, tau, frags, -1.0, patches, out=outr, map_out=bits, lay_in="rsc", lay_out="rsc"), 2 * fat + bits.numel() * 4),
+            ("strip BWD rsc->rsc", lambda: o.fusedg_stage_bwd(g, r, zr, bits, frags, patches, dtp, True, out=outr, lay_in="rsc", lay_out="rsc"), 2 * fat + bits.numel() * 4),
+            ("strip FWD nchw->rsc", lambda: o.fusedg_iter(g, r, z, tau, frags, -1.0, patches, out=outr, lay_out="rsc"), 2 * fat),
             ("strip FWD (no map)", lambda: o.fusedg_iter(g, r, z, tau, frags, -1.0, patches, out=out), 2 * fat),
             ("strip FWD + map", lambda: o.fusedg_iter(g, r, z, tau, frags, -1.0, patches, out=out, map_out=bits), 2 * fat + bits.numel() * 4),
             ("strip FIRST", lambda: o.fusedg_iter(g, r, None, tau, frags, 1.0, patches, out=out), fat),
