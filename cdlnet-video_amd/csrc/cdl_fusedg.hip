@@ -961,6 +961,29 @@ int prep_pairs(const cdl_geom *g, const Plan &pl, const float *const *w1, const 
     return 0;
 }
 
+// Which kernel serves a geometry: 0 = the tile kernel k_stage_g (this file), 1 = cdl_strip.hip (one image channel, stride
+// 1 / 2, M <= 192), 2 = cdl_stripg.hip (the tile kernel's shapes in the strip decomposition, reading the same prepared
+// fragments; opt-in with CDL_FUSEDG_STRIP=1: measured at parity with the tile kernel forward and behind it in the reverse
+// mode).
+struct Route {
+    int kind;
+    Plan pl;
+    cdl_strip_plan sp;
+    cdl_stripg_plan gp;
+};
+bool route_for(const cdl_geom *g, Route *rt)
+{
+    if (plan_for(g, &rt->pl)) {
+        rt->kind = (cdl_opts().fusedg_strip && cdl_stripg_plan_for(g, &rt->gp)) ? 2 : 0;
+        return true;
+    }
+    if (cdl_strip_plan_for(g, &rt->sp)) {
+        rt->kind = 1;
+        return true;
+    }
+    return false;
+}
+
 // layouts of the strip kernel's fat operands from the precision word: CDL_LAY_NCHW or CDL_LAY_RSC on either side
 bool strip_layouts(int precision, int *lay_in, int *lay_out)
 {
@@ -988,41 +1011,36 @@ int cdl_fusedg_set_timeline(void *buf)
  * subbands -- the shipped CDLNet-s2030 architecture) go through the same entry points. */
 int cdl_fusedg_supported(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    return (plan_for(g, &pl) || cdl_strip_plan_for(g, &sp)) ? 1 : 0;
+    Route rt;
+    return route_for(g, &rt) ? 1 : 0;
 }
 
 size_t cdl_fusedg_frag_bytes(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.frag_uint4 * 16 : 0;
-    return pl.frag_uint4 * 16;
+    Route rt;
+    if (!route_for(g, &rt)) return 0;
+    return (rt.kind == 1 ? rt.sp.frag_uint4 : rt.pl.frag_uint4) * 16;
 }
 
 size_t cdl_fusedg_patch_floats(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.patch_floats : 0;
-    return pl.patch_floats;
+    Route rt;
+    if (!route_for(g, &rt)) return 0;
+    return rt.kind == 1 ? rt.sp.patch_floats : rt.kind == 2 ? rt.gp.patch_floats : rt.pl.patch_floats;
 }
 
 size_t cdl_fusedg_tiles(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.items : 0;
-    return pl.tiles;
+    Route rt;
+    if (!route_for(g, &rt)) return 0;
+    return rt.kind == 1 ? rt.sp.items : rt.kind == 2 ? rt.gp.items : rt.pl.tiles;
 }
 
 size_t cdl_fusedg_map_words(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    if (!plan_for(g, &pl)) return cdl_strip_plan_for(g, &sp) ? sp.map_words : 0;
-    return (size_t)g->N * 4 * g->D * g->H * g->W;
+    Route rt;
+    if (!route_for(g, &rt)) return 0;
+    return rt.kind == 1 ? rt.sp.map_words : (size_t)g->N * 4 * g->D * g->H * g->W;
 }
 
 /* The layout the sweeps should keep z[0..K-2] and the du buffers in: CDL_LAY_RSC for the strip kernel's shapes when the
@@ -1030,45 +1048,47 @@ size_t cdl_fusedg_map_words(const cdl_geom *g)
  * code tensor in that layout. */
 int cdl_fusedg_code_layout(const cdl_geom *g)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    if (plan_for(g, &pl) || !cdl_strip_plan_for(g, &sp)) return CDL_LAY_NCHW;
+    Route rt;
+    if (!route_for(g, &rt) || rt.kind == 0) return CDL_LAY_NCHW;
     return cdl_mfma_wgrad_takes(g) ? CDL_LAY_RSC : CDL_LAY_NCHW;
 }
 
 size_t cdl_fusedg_code_floats(const cdl_geom *g, int layout)
 {
-    cdl_strip_plan sp;
-    if (layout == CDL_LAY_RSC) return cdl_strip_plan_for(g, &sp) ? cdl_strip_rsc_floats(g, sp) : 0;
+    Route rt;
+    if (layout == CDL_LAY_RSC) {
+        if (!route_for(g, &rt)) return 0;
+        return rt.kind == 1 ? cdl_strip_rsc_floats(g, rt.sp) : rt.kind == 2 ? cdl_stripg_rsc_floats(g, rt.gp) : 0;
+    }
     return (size_t)g->N * g->M * (g->D / g->sd) * (g->H / g->sh) * (g->W / g->sw);
 }
 
 int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
     if (!wA || !wB || !frags) return CDL_EINVAL;
     const float *a[1] = {wA}, *b[1] = {wB};
-    if (strip) return cdl_strip_prep_pairs(g, sp, a, b, 1, 1, frags, S(stream));
-    return prep_pairs(g, pl, a, b, 1, 1, frags, S(stream));
+    if (rt.kind == 1) return cdl_strip_prep_pairs(g, rt.sp, a, b, 1, 1, frags, S(stream));
+    return prep_pairs(g, rt.pl, a, b, 1, 1, frags, S(stream));
 }
 
 int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin, const float *tau, const void *frags,
                         float sgn, float *zout, float *patches, unsigned *map_out, int precision, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
+    const Plan &pl = rt.pl;
     if (!r || !tau || !frags || !zout || !patches || zout == zin) return CDL_EINVAL;
-    if (strip) {
+    if (rt.kind != 0) {
         int li, lo;
         if (!strip_layouts(precision, &li, &lo)) return CDL_EINVAL;
         if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
-        return cdl_strip_stage(g, sp, zin ? 0 : 1, r, zin, tau, frags, sgn, zout, patches, map_out, nullptr, 1,
-                               (precision >> 4) & 1, li, lo, S(stream));
+        if (rt.kind == 1)
+            return cdl_strip_stage(g, rt.sp, zin ? 0 : 1, r, zin, tau, frags, sgn, zout, patches, map_out, nullptr, 1,
+                                   (precision >> 4) & 1, li, lo, S(stream));
+        return cdl_stripg_stage(g, rt.gp, zin ? 0 : 1, r, zin, tau, frags, sgn, zout, patches, map_out, nullptr, 1,
+                                (precision >> 4) & 1, li, lo, S(stream));
     }
     GParams p = {};
     p.r = r; p.zin = zin; p.zout = zout; p.tau = tau; p.map = map_out;
@@ -1081,18 +1101,20 @@ int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base
                          const void *frags, float *du_out, float *patches, float *dtau_partial, int do_synth,
                          int precision, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
+    const Plan &pl = rt.pl;
     if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
-    if (strip) {
+    if (rt.kind != 0) {
         int li, lo;
         if (!strip_layouts(precision, &li, &lo)) return CDL_EINVAL;
         if ((precision & 15) != 0) return CDL_EUNSUPPORTED;
-        return cdl_strip_stage(g, sp, 2, thin, base, nullptr, frags, 1.0f, du_out, patches, const_cast<unsigned *>(map),
-                               dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, li, lo, S(stream));
+        if (rt.kind == 1)
+            return cdl_strip_stage(g, rt.sp, 2, thin, base, nullptr, frags, 1.0f, du_out, patches, const_cast<unsigned *>(map),
+                                   dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, li, lo, S(stream));
+        return cdl_stripg_stage(g, rt.gp, 2, thin, base, nullptr, frags, 1.0f, du_out, patches, const_cast<unsigned *>(map),
+                                dtau_partial, do_synth ? 1 : 0, (precision >> 4) & 1, li, lo, S(stream));
     }
     GParams p = {};
     p.r = thin; p.zin = base; p.map = const_cast<unsigned *>(map); p.zout = du_out; p.dtau = dtau_partial;
@@ -1104,12 +1126,12 @@ int cdl_fusedg_stage_bwd(const cdl_geom *g, const float *thin, const float *base
 int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *mask, const float *sub, float alpha,
                         float *out, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
+    const Plan &pl = rt.pl;
     if (!patches || !out) return CDL_EINVAL;
-    if (strip) return cdl_strip_assemble(g, sp, patches, mask, sub, alpha, out, S(stream));
+    if (rt.kind == 1) return cdl_strip_assemble(g, rt.sp, patches, mask, sub, alpha, out, S(stream));
+    if (rt.kind == 2) return cdl_stripg_assemble(g, rt.gp, patches, mask, sub, alpha, out, S(stream));
     if ((g->W & 3) == 0 && !cdl_opts().scalar_assemble) {
         dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)((g->H + 3) / 4), (unsigned)(g->N * g->C * g->D));
 #define CDL_ASM4(P_) k_assemble_g4<P_><<<grid, 256, 0, S(stream)>>>(patches, mask, sub, alpha, out, g->N, g->C, g->D, g->H, g->W, g->Pd, pl.tilesX, pl.tilesY)
@@ -1128,12 +1150,11 @@ int cdl_fusedg_assemble(const cdl_geom *g, const float *patches, const float *ma
 int cdl_fusedg_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c, float *dt0, float *dt1,
                            void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
     if (!dtau_partial || !dt0 || !dt1) return CDL_EINVAL;
-    const int per_img = strip ? sp.nsx * sp.nsy : g->D * pl.tilesX * pl.tilesY;
+    const int per_img = rt.kind == 1 ? rt.sp.nsx * rt.sp.nsy
+                        : rt.kind == 2 ? g->D * rt.gp.nsx * rt.gp.nsy : g->D * rt.pl.tilesX * rt.pl.tilesY;
     k_dtau_reduce_g<<<(g->M + 3) / 4, 1024, 0, S(stream)>>>(dtau_partial, c, dt0, dt1, g->N, per_img, g->M);
     CDL_LAUNCH_CHECK();
     return 0;
@@ -1144,10 +1165,11 @@ int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *m
                        const float *const *wA, const float *const *wB, float *const *z, float *const *r,
                        unsigned *const *maps, float *xp, void *frags, float *patches, int precision, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
+    const Plan &pl = rt.pl;
+    const cdl_strip_plan &sp = rt.sp;
+    const bool strip = rt.kind == 1;
     if (K < 1 || !yp || !tau || !wA || !wB || !z || !xp || !frags || !patches || (K > 1 && !r)) return CDL_EINVAL;
     const size_t nm = (size_t)g->N * g->M;
     const int snake = cdl_opts().fused_snake;
@@ -1159,7 +1181,7 @@ int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *m
     // CDL_LAYOUT_IN(precision): the layout of z[0..K-2] (strip shapes: CDL_LAY_RSC allowed); z[K-1] is always the
     // reference's (N,M,..) layout
     const int lay = (precision >> 5) & 3, pbase = precision & 15;
-    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(strip && lay == CDL_LAY_RSC))) return CDL_EINVAL;
+    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(rt.kind != 0 && lay == CDL_LAY_RSC))) return CDL_EINVAL;
     for (int k = 0; k < K; ++k) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         const int flags = pbase | ((k & 1) && snake ? CDL_TILES_REVERSED : 0) | CDL_LAYOUT_IN(k ? lay : CDL_LAY_NCHW) |
@@ -1187,10 +1209,11 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
                         float *const *dB, float *dt, float *du0, float *du1, float *q, void *frags, float *patches,
                         float *dtau_partial, float *wgrad_ws, size_t wgrad_ws_floats, int precision, void *stream)
 {
-    Plan pl;
-    cdl_strip_plan sp;
-    const bool strip = !plan_for(g, &pl);
-    if (strip && !cdl_strip_plan_for(g, &sp)) return CDL_EUNSUPPORTED;
+    Route rt;
+    if (!route_for(g, &rt)) return CDL_EUNSUPPORTED;
+    const Plan &pl = rt.pl;
+    const cdl_strip_plan &sp = rt.sp;
+    const bool strip = rt.kind == 1;
     if (K < 1 || !yp || !wA || !wB || !z || !maps || !g_xp || !dA || !dB || !dt || !du0 || !du1 || !q || !frags ||
         !patches || !dtau_partial || (K > 1 && !r))
         return CDL_EINVAL;
@@ -1201,7 +1224,7 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
     // CDL_LAYOUT_IN(precision): the layout of z[0..K-2] and of the du buffers (strip shapes: CDL_LAY_RSC allowed, when
     // the matrix-core filter-gradient kernel takes the geometry: its VALU fallbacks read the reference layout only)
     const int lay = (precision >> 5) & 3;
-    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(strip && lay == CDL_LAY_RSC && cdl_mfma_wgrad_takes(g))))
+    if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(rt.kind != 0 && lay == CDL_LAY_RSC && cdl_mfma_wgrad_takes(g))))
         return CDL_EINVAL;
     const int rsc = lay == CDL_LAY_RSC;
     int rc = cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], wgrad_ws, wgrad_ws_floats, stream);      // dB_0 = z_K (x) dL/d(D z_K)

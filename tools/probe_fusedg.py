@@ -30,9 +30,14 @@ frags = o.fusedg_prep(g, w, w)
 patches = o.fusedg_patches(g, "cuda")
 out = torch.empty_like(z)
 fat = z.numel() * 4
-names = {0: "full kernel", 1: "no thin staging after the first tile", 2: "no analysis GEMM", 4: "no synthesis / col2im",
-         8: "no fat loads", 16: "no fat stores", 24: "no fat traffic", 32: "no patch combine", 6: "no GEMMs at all",
-         63: "tile loop skeleton only"}
+tile = os.environ.get("CDL_FUSEDG_STRIP", "0") in ("", "0")
+if tile:      # the tile kernel k_stage_g (cdl_fusedg.hip)
+    names = {0: "full kernel", 1: "no thin staging after the first tile", 4: "no synthesis / col2im", 8: "no fat loads",
+             16: "no fat stores", 24: "no fat traffic", 32: "no patch combine", 61: "tile loop skeleton only"}
+else:         # the strip kernel k_stripg (cdl_stripg.hip), the default
+    names = {0: "full kernel", 1: "no fat loads", 2: "no fat stores", 3: "no fat traffic", 4: "no analysis-like MFMAs",
+             8: "no synthesis-like MFMAs", 12: "no MFMAs at all", 16: "no col2im", 32: "no im2col gather",
+             60: "no MFMA, col2im, gather (epilogue + traffic)", 63: "row loop skeleton + epilogue VALU only"}
 rows = []
 for rnd in range(3):
     for dbg, name in names.items():
@@ -52,5 +57,5 @@ os.environ["CDL_FUSED_DEBUG"] = "0"
 cva._lib.reload_options()
 for dbg, name in names.items():
     ms = sorted(t for d, _, t in rows if d == dbg)[1]
-    print(json.dumps({"shape": cfg, "debug_bits": dbg, "variant": name, "ms": round(ms, 4),
+    print(json.dumps({"shape": cfg, "kernel": "k_stage_g (tile)" if tile else "k_stripg (strip)", "debug_bits": dbg, "variant": name, "ms": round(ms, 4),
                       "GBps_if_full_traffic": round(2 * fat / ms / 1e6, 1)}), flush=True)
