@@ -239,6 +239,12 @@ def main():
 
 def run_rank(args):
     global torch, dist
+    # stdout carries the ONE JSON line and nothing else: libraries underneath print there too (gloo's "[Gloo] Rank 0 is
+    # connected ..." banner, RCCL with NCCL_DEBUG set), so file descriptor 1 is pointed at stderr for the whole run and
+    # the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -407,10 +413,12 @@ def run_rank(args):
                              "psnr_cpu": round(cva.psnr(xs, xref), 4),
                              "psnr_gpu": round(cva.psnr(xs, xo.cpu()), 4),
                              "psnr_noisy": round(cva.psnr(xs, ys), 4)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    os.close(result_fd)
 
 
 if __name__ == "__main__":

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 
     constexpr int M = 32 * MT;
     constexpr int FA = MT * 4, FB = 4 * MT;
-    constexpr int NFRAG = (PREC == 0 ? 2 : 1) * (FA + FB);   // bf16 mode stages only the hi fragments
+    constexpr int NFRAG = (PREC != 1 ? 2 : 1) * (FA + FB);   // bf16 mode stages only the hi fragments
     constexpr int NSTG = (RTH * RTW + NT - 1) / NT;          // thin-tile elements staged per thread
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wxi = wid % WX, wyi = wid / WX;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         uint4 *z4 = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < (LDS_RT + LDS_RSUM) / 16; i += NT) z4[i] = make_uint4(0, 0, 0, 0);
         uint4 *wdst = reinterpret_cast<uint4 *>(smem + LDS_RT + LDS_RSUM);
-        if (PREC == 0) {
+        if (PREC != 1) {
             for (int i = tid; i < NFRAG * 64; i += NT) wdst[i] = p.frags[i];
         } else {                                            // [A hi | B hi] compacted
             for (int i = tid; i < FA * 64; i += NT) wdst[i] = p.frags[i];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             for (int q = 0; q < 4; ++q)
                 if (yy - q >= 0) {
                     rt[(0 * 4 + q) * COPY + xx * PITCH + (yy - q)] = hh;
-                    if (PREC == 0) rt[(1 * 4 + q) * COPY + xx * PITCH + (yy - q)] = ll;
+                    if (PREC != 1) rt[(1 * 4 + q) * COPY + xx * PITCH + (yy - q)] = ll;
                 }
         }
     };
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     // fragment offsets inside the LDS weight area
     constexpr int OFF_AH = 0;
     constexpr int OFF_AL = FA;                               // split3 only
-    constexpr int OFF_BH = (PREC == 0 ? 2 * FA : FA);
+    constexpr int OFF_BH = (PREC != 1 ? 2 * FA : FA);
     constexpr int OFF_BL = 2 * FA + FB;                      // split3 only
     auto wfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wl[f * 64 + lane]); };
 
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
             const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ph);
             const bf16x4 a1 = *reinterpret_cast<const bf16x4 *>(ph + 4);
             rh[ks] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            if (PREC == 0) {
+            if (PREC != 1) {
                 const __bf16 *pl = rt + (1 * 4 + q) * COPY + col * PITCH + e;
                 const bf16x4 b0 = *reinterpret_cast<const bf16x4 *>(pl);
                 const bf16x4 b1 = *reinterpret_cast<const bf16x4 *>(pl + 4);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 #pragma unroll
             for (int R = 0; R < MT; ++R) {
                 wh[0][R] = wfrag(OFF_AH + R * 4);
-                if (PREC == 0) wlo[0][R] = wfrag(OFF_AL + R * 4);
+                if (PREC != 1) wlo[0][R] = wfrag(OFF_AL + R * 4);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -573,14 +573,18 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 #pragma unroll
                     for (int R = 0; R < MT; ++R) {
                         wh[nx][R] = wfrag(OFF_AH + R * 4 + ks + 1);
-                        if (PREC == 0) wlo[nx][R] = wfrag(OFF_AL + R * 4 + ks + 1);
+                        if (PREC != 1) wlo[nx][R] = wfrag(OFF_AL + R * 4 + ks + 1);
                     }
                 }
-                if (PREC == 0) {
+                if (PREC != 1) {
 #pragma unroll
                     for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[cu][R], rh[ks], acc[R], 0, 0, 0);
 #pragma unroll
                     for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cu][R], rl[ks], acc[R], 0, 0, 0);
+                    if (PREC == 2) {                                     // split4: the lo * lo term as well
+#pragma unroll
+                        for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[cu][R], rl[ks], acc[R], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cu][R], rh[ks], acc[R], 0, 0, 0);
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 #pragma unroll
             for (int Rp = 0; Rp < 2; ++Rp) {
                 bwh[0][Rp] = wfrag(OFF_BH + Rp * 2 * MT);
-                if (PREC == 0) bwl[0][Rp] = wfrag(OFF_BL + Rp * 2 * MT);
+                if (PREC != 1) bwl[0][Rp] = wfrag(OFF_BL + Rp * 2 * MT);
             }
 #pragma unroll
             for (int q = 0; q < 2 * MT; ++q) {
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 #pragma unroll
                     for (int Rp = 0; Rp < 2; ++Rp) {
                         bwh[nx][Rp] = wfrag(OFF_BH + Rp * 2 * MT + q + 1);
-                        if (PREC == 0) bwl[nx][Rp] = wfrag(OFF_BL + Rp * 2 * MT + q + 1);
+                        if (PREC != 1) bwl[nx][Rp] = wfrag(OFF_BL + Rp * 2 * MT + q + 1);
                     }
                 }
                 bf16x8 zh, zl;
@@ -676,14 +680,18 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                     const float val = acc[R][8 * s + jj];
                     const __bf16 hh = (__bf16)val;
                     zh[jj] = hh;
-                    if (PREC == 0 && LOUT != LAY_BLK16) zl[jj] = (__bf16)(val - (float)hh);   // a bf16-stored code has no lo part
+                    if (PREC != 1 && LOUT != LAY_BLK16) zl[jj] = (__bf16)(val - (float)hh);   // a bf16-stored code has no lo part
                 }
-                if (PREC == 0) {
+                if (PREC != 1) {
 #pragma unroll
                     for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwl[cu][Rp], zh, D[Rp], 0, 0, 0);
                     if (LOUT != LAY_BLK16) {
 #pragma unroll
                         for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwh[cu][Rp], zl, D[Rp], 0, 0, 0);
+                        if (PREC == 2) {
+#pragma unroll
+                            for (int Rp = 0; Rp < 2; ++Rp) D[Rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bwl[cu][Rp], zl, D[Rp], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
                 for (int s = 0; s < 4; ++s)
                     if (xx - s >= 0) {
                         thin[((op * 2 + 0) * 4 + s) * TCOPY + yy * TPITCH + xx - s] = hh;
-                        if (PREC == 0) thin[((op * 2 + 1) * 4 + s) * TCOPY + yy * TPITCH + xx - s] = ll;
+                        if (PREC != 1) thin[((op * 2 + 1) * 4 + s) * TCOPY + yy * TPITCH + xx - s] = ll;
                     }
             }
         }
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
                     const int slot = (2 * qv + h) ^ ((c >> 1) & 7);      // 8-byte slot of channels 8qv+4h..+3
                     __bf16 *dst = wimg + (size_t)(R * 2) * IMG_ELEMS + c * 32 + slot * 4;
                     *reinterpret_cast<bf16x4 *>(dst) = hi4;
-                    if (PREC == 0 && LAY != LAY_BLK16) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
+                    if (PREC != 1 && LAY != LAY_BLK16) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1035,7 +1043,7 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
                     const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ph);
                     const bf16x4 a1 = *reinterpret_cast<const bf16x4 *>(ph + 4);
                     Bh[tt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (PREC == 0) {
+                    if (PREC != 1) {
                         const __bf16 *pl = ph + 4 * TCOPY;
                         const bf16x4 b0 = *reinterpret_cast<const bf16x4 *>(pl);
                         const bf16x4 b1 = *reinterpret_cast<const bf16x4 *>(pl + 4);
@@ -1055,18 +1063,19 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
                         const __bf16 *src = wimg + (size_t)(R * 2) * IMG_ELEMS + row * 32 + slot * 4;
                         part[0][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                             (__attribute__((address_space(3))) bf16x4 *)(src));
-                        if (PREC == 0 && LAY != LAY_BLK16)
+                        if (PREC != 1 && LAY != LAY_BLK16)
                             part[1][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                 (__attribute__((address_space(3))) bf16x4 *)(src + IMG_ELEMS));
                     }
                     const bf16x8 Ah = __builtin_shufflevector(part[0][0], part[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     bf16x8 Al;
-                    if (PREC == 0 && LAY != LAY_BLK16) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (PREC != 1 && LAY != LAY_BLK16) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        if (PREC == 0) {
+                        if (PREC != 1) {
                             if (LAY != LAY_BLK16) acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], acc[R][tt], 0, 0, 0);
                             acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[tt], acc[R][tt], 0, 0, 0);
+                            if (PREC == 2 && LAY != LAY_BLK16) acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bl[tt], acc[R][tt], 0, 0, 0);
                         }
                         acc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[tt], acc[R][tt], 0, 0, 0);
                     }
@@ -1177,7 +1186,8 @@ inline int debug_flags() { return cdl_opts().fused_debug; }
 inline int tiles_x(const cdl_geom *g) { return (g->W + TW - 1) / TW; }
 inline int tiles_y(const cdl_geom *g) { return (g->H + TH - 1) / TH; }
 
-// `precision` argument of the entry points: bits 0-3 arithmetic (0 split-bf16 x3, 1 plain bf16), bit 4
+// `precision` argument of the entry points: bits 0-3 arithmetic (0 split-bf16 x3, 1 plain bf16, 2 split-bf16 x4: the
+// lo * lo products as well -- exact fp32 products, for objectives that difference two forward passes), bit 4
 // CDL_TILES_REVERSED, bits 5-6 layout of the fat INPUT(s), bits 7-8 layout of the fat OUTPUT (LAY_*)
 struct Flags {
     int prec, rev, lin, lout;
@@ -1190,7 +1200,7 @@ inline Flags parse_flags(int precision)
     f.rev = (precision >> 4) & 1;
     f.lin = (precision >> 5) & 3;
     f.lout = (precision >> 7) & 3;
-    f.ok = (precision >> 9) == 0 && (f.prec == 0 || f.prec == 1) && f.lin <= LAY_BLK16 && f.lout <= LAY_BLK16;
+    f.ok = (precision >> 9) == 0 && (f.prec == 0 || f.prec == 1 || f.prec == 2) && f.lin <= LAY_BLK16 && f.lout <= LAY_BLK16;
     return f;
 }
 
@@ -1242,10 +1252,12 @@ int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, const Flag
     if (cap > 0 && (size_t)cap < cus) cus = (size_t)cap;
     dim3 grid((unsigned)(tiles < cus ? tiles : cus));
     if (g->M == 64)
-        return f.prec == 0 ? launch_stage<2, 0>(p, mode, f.lin, f.lout, grid, st)
-                           : launch_stage<2, 1>(p, mode, f.lin, f.lout, grid, st);
-    return f.prec == 0 ? launch_stage<1, 0>(p, mode, f.lin, f.lout, grid, st)
-                       : launch_stage<1, 1>(p, mode, f.lin, f.lout, grid, st);
+        return f.prec == 0   ? launch_stage<2, 0>(p, mode, f.lin, f.lout, grid, st)
+               : f.prec == 1 ? launch_stage<2, 1>(p, mode, f.lin, f.lout, grid, st)
+                             : launch_stage<2, 2>(p, mode, f.lin, f.lout, grid, st);
+    return f.prec == 0   ? launch_stage<1, 0>(p, mode, f.lin, f.lout, grid, st)
+           : f.prec == 1 ? launch_stage<1, 1>(p, mode, f.lin, f.lout, grid, st)
+                         : launch_stage<1, 2>(p, mode, f.lin, f.lout, grid, st);
 }
 
 int wgrad_grid(const cdl_geom *g)
@@ -1397,8 +1409,12 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     p.numTiles = p.N * p.tilesX * p.tilesY;
     const int G = wgrad_grid(g);
     int rc;
-    if (g->M == 64) rc = f.prec == 0 ? launch_wgrad<2, 0>(p, f.lin, G, S(stream)) : launch_wgrad<2, 1>(p, f.lin, G, S(stream));
-    else rc = f.prec == 0 ? launch_wgrad<1, 0>(p, f.lin, G, S(stream)) : launch_wgrad<1, 1>(p, f.lin, G, S(stream));
+    if (g->M == 64)
+        rc = f.prec == 0 ? launch_wgrad<2, 0>(p, f.lin, G, S(stream))
+             : f.prec == 1 ? launch_wgrad<2, 1>(p, f.lin, G, S(stream)) : launch_wgrad<2, 2>(p, f.lin, G, S(stream));
+    else
+        rc = f.prec == 0 ? launch_wgrad<1, 0>(p, f.lin, G, S(stream))
+             : f.prec == 1 ? launch_wgrad<1, 1>(p, f.lin, G, S(stream)) : launch_wgrad<1, 2>(p, f.lin, G, S(stream));
     if (rc) return rc;
     const int total = 2 * g->M * g->Ph * g->Pw;
     k_wgrad_reduce<<<(total + 31) / 32, 1024, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,

@@ -206,7 +206,8 @@ __host__ __device__ inline Carve carve(int MT, int KS, int KQ, int G, int prec)
     return c;
 }
 
-template <int P, int G, int MT, int MODE>
+// FOUR: split-bf16 x4 -- the lo * lo products as well (exact fp32 products); precision 2 of the entry points.
+template <int P, int G, int MT, int MODE, bool FOUR = false>
 __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
 {
     constexpr int PREC = 0;                                  // split-bf16 x3 (a plain-bf16 variant is not built)
@@ -491,6 +492,10 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                     for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fc][R], bh[cu], acc[R], 0, 0, 0);
 #pragma unroll
                     for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fc][R], bl[cu], acc[R], 0, 0, 0);
+                    if (FOUR) {
+#pragma unroll
+                        for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fc][R], bl[cu], acc[R], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int R = 0; R < MT; ++R) acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fc][R], bh[cu], acc[R], 0, 0, 0);
                 }
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(NT) void k_stage_g(GParams p)
                     for (int q = 0; q < NQ; ++q) {
                         const int f = t * NQ + q;
                         const bf16x8 wh = bfrag(f), wl = bfrag(OFF_BL + f);
+                        if (FOUR) Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zl[q], Dt, 0, 0, 0);
                         Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, zh[q], Dt, 0, 0, 0);
                         Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zl[q], Dt, 0, 0, 0);
                         Dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh[q], Dt, 0, 0, 0);
@@ -884,16 +890,16 @@ bool plan_for(const cdl_geom *g, Plan *pl)
     return true;
 }
 
-template <int P, int G, int MT, int MODE>
+template <int P, int G, int MT, int MODE, bool FOUR = false>
 int launch_one(const GParams &p, const Plan &pl, hipStream_t st)
 {
     const int lds = carve<P>(MT, pl.KS, pl.KQ, G, 0).total;
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage_g<P, G, MT, MODE>, lds)) return rc;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage_g<P, G, MT, MODE, FOUR>, lds)) return rc;
     size_t cus = (size_t)cdl_cu_count();
     const int cap = cdl_opts().fused_grid;
     if (cap > 0 && (size_t)cap < cus) cus = (size_t)cap;
     const unsigned grid = (unsigned)(pl.tiles < cus ? pl.tiles : cus);
-    k_stage_g<P, G, MT, MODE><<<grid, NT, lds, st>>>(p);
+    k_stage_g<P, G, MT, MODE, FOUR><<<grid, NT, lds, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -903,7 +909,11 @@ int launch_mode(const GParams &p, const Plan &pl, int mode, hipStream_t st)
 {
     if (mode == MODE_FWD) return launch_one<P, G, MT, MODE_FWD>(p, pl, st);
     if (mode == MODE_FIRST) return launch_one<P, G, MT, MODE_FIRST>(p, pl, st);
-    return launch_one<P, G, MT, MODE_BWD>(p, pl, st);
+    if (mode == MODE_BWD) return launch_one<P, G, MT, MODE_BWD>(p, pl, st);
+    // + 3: split-bf16 x4
+    if (mode == MODE_FWD + 3) return launch_one<P, G, MT, MODE_FWD, true>(p, pl, st);
+    if (mode == MODE_FIRST + 3) return launch_one<P, G, MT, MODE_FIRST, true>(p, pl, st);
+    return launch_one<P, G, MT, MODE_BWD, true>(p, pl, st);
 }
 
 template <int P, int G>
@@ -929,7 +939,8 @@ int dispatch(const cdl_geom *g, GParams &p, const Plan &pl, int mode, int precis
     p.rev = (precision >> 4) & 1;
     CDL_DBG_FIELD(p.dbg = cdl_opts().fused_debug;)
     if ((precision >> 5) != 0) return CDL_EINVAL;
-    if ((precision & 15) != 0) return CDL_EUNSUPPORTED;      // split-bf16 x3 only
+    if ((precision & 15) == 2) mode += 3;                    // split-bf16 x4
+    else if ((precision & 15) != 0) return CDL_EUNSUPPORTED;  // otherwise split-bf16 x3
     p.N = g->N; p.C = g->C; p.M = g->M; p.D = g->D; p.H = g->H; p.W = g->W; p.Pd = g->Pd;
     p.tilesX = pl.tilesX; p.tilesY = pl.tilesY; p.KS = pl.KS;
     if (pl.P == 3) return launch_p<3>(p, pl, mode, st);
@@ -1180,7 +1191,12 @@ int cdl_fusedg_forward(const cdl_geom *g, int K, const float *yp, const float *m
     if (rc) return rc;
     // CDL_LAYOUT_IN(precision): the layout of z[0..K-2] (strip shapes: CDL_LAY_RSC allowed); z[K-1] is always the
     // reference's (N,M,..) layout
-    const int lay = (precision >> 5) & 3, pbase = precision & 15;
+    const int lay = (precision >> 5) & 3;
+    // arithmetic of the tile kernel: split-bf16 x3 unless the caller (precision 2) or CDL_FUSEDG_PREC=2 asks for all four
+    // products.  (Round 3 tested the round-2 hypothesis that the dropped lo * lo products are what shows as 2e-4 in cfg4's
+    // dB_k: with x4 in both sweeps the figure does not move -- tools/debug_cfg4.py, DESIGN.md section 3 -- so x3 stays.)
+    const int forced = cdl_opts().fusedg_bwd_prec;
+    const int pbase = (rt.kind == 0 && (forced == 0 || forced == 2)) ? forced : (precision & 15);
     if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(rt.kind != 0 && lay == CDL_LAY_RSC))) return CDL_EINVAL;
     for (int k = 0; k < K; ++k) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
@@ -1227,6 +1243,8 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
     if ((precision >> 7) != 0 || (lay != CDL_LAY_NCHW && !(rt.kind != 0 && lay == CDL_LAY_RSC && cdl_mfma_wgrad_takes(g))))
         return CDL_EINVAL;
     const int rsc = lay == CDL_LAY_RSC;
+    const int forced = cdl_opts().fusedg_bwd_prec;            // (see cdl_fusedg_forward)
+    const int bprec = (rt.kind == 0 && (forced == 0 || forced == 2)) ? forced : (precision & 15);
     int rc = cdl_wgrad(g, z[K - 1], nullptr, g_xp, 1.0f, dB[0], wgrad_ws, wgrad_ws_floats, stream);      // dB_0 = z_K (x) dL/d(D z_K)
     if (rc) return rc;
     const float *thin = g_xp, *base = g_z;
@@ -1238,7 +1256,7 @@ int cdl_fusedg_backward(const cdl_geom *g, int K, const float *yp, const float *
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         float *duk = du[flip];
         rc = cdl_fusedg_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
-                                  (precision & 15) | (((K - 1 - k) & 1) ? (sdir ^ CDL_TILES_REVERSED) : sdir) |
+                                  bprec | (((K - 1 - k) & 1) ? (sdir ^ CDL_TILES_REVERSED) : sdir) |
                                       CDL_LAYOUT_IN(k == K - 1 ? CDL_LAY_NCHW : lay) | CDL_LAYOUT_OUT(lay), stream);
         if (rc) return rc;
         rc = cdl_fusedg_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);

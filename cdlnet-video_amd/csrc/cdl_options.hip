@@ -42,6 +42,7 @@ const cdl_options *load_options()
     o->fused_grid = env_int("CDL_FUSED_GRID", 0);
     o->scalar_assemble = env_int("CDL_SCALAR_ASSEMBLE", 0) ? 1 : 0;
     o->fusedg_strip = env_int("CDL_FUSEDG_STRIP", 0) ? 1 : 0;
+    o->fusedg_bwd_prec = env_int("CDL_FUSEDG_PREC", -1);
 #ifdef CDL_ABLATE
     o->fused_debug = env_int("CDL_FUSED_DEBUG", 0);
     o->dense_debug = env_int("CDL_DENSE_DEBUG", 0);

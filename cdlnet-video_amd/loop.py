@@ -20,7 +20,9 @@ from . import ops
 
 # Kernel selection for the forward sweep: "auto" uses the fused MFMA kernels whenever the geometry
 # has one (cdl_fused2d_supported) and the shape-generic kernels otherwise; "generic" forces the latter.
-# PRECISION applies to the fused kernels only: "split3" (fp32-grade, default) or "bf16".
+# PRECISION applies to the fused 2-D kernels only: "split3" (split-bf16 with three products per multiply: fp32-grade, the
+# default), "split4" (all four products: exact fp32 products -- what an objective that differences two forward passes
+# needs, see precision_scope / train.mcsure_loss) or "bf16".
 BACKEND = "auto"
 PRECISION = "split3"
 # How the fused sweeps store the codes that never leave them (z_1..z_{K-1}, du_k): "blocked" (pixel-blocked
@@ -41,6 +43,26 @@ def set_precision(name):
     if name not in ops.PRECISION:
         raise ValueError(name)
     PRECISION = name
+
+
+class precision_scope:
+    """`with precision_scope("split4"): ...` -- the fused 2-D sweeps started inside run in that arithmetic; their reverse
+    sweeps use the arithmetic of their forward whenever backward() is called."""
+
+    def __init__(self, name):
+        if name not in ops.PRECISION:
+            raise ValueError(name)
+        self.name = name
+
+    def __enter__(self):
+        global PRECISION
+        self.saved, PRECISION = PRECISION, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.saved
+        return False
 
 
 def set_code_layout(name):
@@ -181,14 +203,14 @@ def _backward_generic_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_
     return dA, dB
 
 
-def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout=None):
+def _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout=None, precision=None):
     """Reverse sweep from one C call (cdl_fused2d_backward): per iteration one stage launch (1 fat read +
     the 2-bit map of z_{k+1}, 1 fat write), a thin assemble, and one MFMA filter-gradient launch (2 fat
     reads).  maps: the forward's bit maps (rebuilt from the codes when absent); `layout`: that of codes[:-1]."""
     if g_xp is None and g_z is None:
         return [torch.zeros_like(w) for w in A], [torch.zeros_like(w) for w in B]
     return ops.fused_backward(g, yp, mask_p, c, list(A), list(B), list(codes), list(resid), g_xp, g_z, dt,
-                              PRECISION, maps=list(maps) if maps else None, layout=layout or CODE_LAYOUT)
+                              precision or PRECISION, maps=list(maps) if maps else None, layout=layout or CODE_LAYOUT)
 
 
 def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=None, layout="nchw"):
@@ -256,6 +278,7 @@ class UnrolledISTA(torch.autograd.Function):
         elif ctx.fused:
             # codes handed to the caller (forward_generator) must be (N,M,H,W); otherwise they stay internal
             ctx.layout = "nchw" if want_codes else CODE_LAYOUT
+            ctx.precision = PRECISION                  # the reverse sweep runs in the forward's arithmetic
             xp, z, codes, resid, maps = _forward_fused(g, yp, mask_p, tau, A, B, keep or want_codes, keep, ctx.layout)
         else:
             xp, z, codes, resid, maps = _forward_generic(g, yp, mask_p, tau, A, B, keep or want_codes, keep)
@@ -296,7 +319,7 @@ class UnrolledISTA(torch.autograd.Function):
             dA, dB = _backward_fusedg(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps, layout=ctx.layout)
         elif ctx.fused:                                # a loss on z only is a zero image gradient to the sweep
             dA, dB = _backward_fused(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt, maps=maps,
-                                     layout=ctx.layout)
+                                     layout=ctx.layout, precision=ctx.precision)
         else:
             dA, dB = _backward_generic(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z, dt)
 

@@ -520,7 +520,7 @@ def gabor_filter_banks_bwd(params, dws, P, transposes):
 
 
 # ------------------------------------------------------------------------------------------ fused MFMA path
-PRECISION = {"split3": 0, "bf16": 1}
+PRECISION = {"split3": 0, "bf16": 1, "split4": 2}
 # layouts of the fat tensors that stay inside a fused sweep (include/cdlnet_hip.h, CDL_LAY_*): "nchw" is the
 # reference's layout, "blocked" the pixel-blocked fp32 layout (same values, 16-byte accesses, the default),
 # "blocked_bf16" opt-in bf16 STORAGE of the codes (half the bytes; outside the 1e-5 parity gate)

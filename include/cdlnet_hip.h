@@ -307,7 +307,8 @@ int cdl_gabor_filters_bwd(const float *alpha, const float *a, const float *w0, c
  *     cdl_fused2d_assemble :  patches  ->  r_{k+1} = mask * (B_next z_{k+1}) - yp      (thin)
  * For k = 0 pass r = yp, zin = NULL, sgn = +1 (net.py:85); for k >= 1 sgn = -1.  For the last
  * iteration B_next is D = B_0 and assemble(mask = sub = NULL) yields D z_K (net.py:90).
- * precision: 0 = split-bf16 (hi+lo operands, 3 MFMAs per product, fp32-grade), 1 = plain bf16. */
+ * precision: 0 = split-bf16 (hi+lo operands, 3 MFMAs per product, fp32-grade), 1 = plain bf16, 2 = split-bf16 with all
+ * four products (exact fp32 products; for objectives that difference two forward passes, e.g. MC-SURE). */
 int cdl_fused2d_supported(const cdl_geom *g);              /* 1 if this geometry has a fused kernel */
 size_t cdl_fused2d_frag_bytes(int M);                      /* bytes of one prepared (A_k, B_next) pair */
 size_t cdl_fused2d_patch_floats(const cdl_geom *g);        /* floats in the patch workspace */
@@ -380,7 +381,8 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
  * cdl_fused2d_* family above: one launch per iteration takes (r_k thin, z_k fat) to (z_{k+1} fat, patches of
  * B_next z_{k+1}); cdl_fusedg_assemble sums the patches over tiles and depth taps and applies alpha, mask, -sub.
  * Codes in the reference's (N,M,D,H,W) layout; map = (N,4,D,H,W) words as cdl_fused2d_support_map describes.
- * precision: 0 (split-bf16 x3) only; CDL_TILES_REVERSED may be OR-ed in. */
+ * precision: 0 (split-bf16 x3), or 2 (split-bf16 x4: all four products) on the tile kernel; CDL_TILES_REVERSED may be
+ * OR-ed in. */
 int cdl_fusedg_supported(const cdl_geom *g);
 /* Profiling hook (not part of the reference surface): while buf != NULL every cdl_fusedg stage launch records
  * s_memtime stamps of its workgroup 0 into buf[8 waves][256] (16 KB of device memory).  NULL switches it off. */

@@ -477,16 +477,18 @@ def loss_and_grads(sd, x, y, *, K, P, s, sigma, adaptive, mask=None, ndim=2, gab
     return float(loss.detach()), grads, xhat.detach()
 
 
-def mcsure_loss_and_grads(sd, obsrv, b, *, K, P, s, sigma, adaptive, mask=None, ndim=2, h=1e-3):
+def mcsure_loss_and_grads(sd, obsrv, b, *, K, P, s, sigma, adaptive, mask=None, ndim=2, h=1e-3, supports=None,
+                          supports_b=None):
     """The unsupervised objective of train.py:87-93 (one extra forward at obsrv + h*b) and its gradients:
-    mean((obsrv - xhat)^2) + 2 * mean((sigma/255)^2 * b * (xhat_b - xhat)) / h."""
+    mean((obsrv - xhat)^2) + 2 * mean((sigma/255)^2 * b * (xhat_b - xhat)) / h.
+    supports / supports_b: prescribed code supports of the two passes (see ista_codes)."""
     keys = trainable(sd, K, False)
     work = dict(sd)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work.update(leaves)
     kw = dict(K=K, P=P, s=s, sigma=sigma, adaptive=adaptive, mask=mask, ndim=ndim)
-    xhat, _ = ista(work, obsrv, **kw)
-    xhat_b, _ = ista(work, obsrv.clone() + h * b, **kw)
+    xhat, _ = ista(work, obsrv, supports=supports, **kw)
+    xhat_b, _ = ista(work, obsrv.clone() + h * b, supports=supports_b, **kw)
     div = 2.0 * torch.mean(((sigma / 255.0) ** 2) * b * (xhat_b - xhat)) / h
     loss = torch.mean((obsrv - xhat) ** 2) + div
     loss.backward()

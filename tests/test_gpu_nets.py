@@ -221,3 +221,43 @@ def test_mcsure_objective_vs_oracle():
         if pname != "g":
             # the divergence term is a difference of two forwards divided by h = 1e-3: fp32 noise is amplified 1000x
             check(f"mcsure grad {pname}", p.grad, ref_grads[pname], 1e-3)
+
+
+@pytest.mark.parametrize("precision", ["split3", "split4"])
+def test_mcsure_gradients_on_the_fused_path_with_both_supports_prescribed(precision):
+    """the per-step MC-SURE gradient of the fused 2-D path (the f12 trajectory's geometry: K=3, M=32,
+    P=5) against autograd of the oracle with the supports of BOTH forward passes prescribed (no support flip can enter;
+    what remains is arithmetic, multiplied by 1/h = 1e3).  Gate 1e-4 of each tensor's maximum (measured: 6.7e-5 / 5.6e-5).  "split4" (all four bf16
+    products) is measured beside the default: the two-term operand split (16-17 significant bits), not the dropped
+    lo * lo product, is the floor, so it buys nothing."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    torch.manual_seed(31)
+    K, M, P = 3, 32, 5
+    net = cva.CDLNet(K=K, M=M, P=P, s=1, C=1, t0=5e-3, adaptive=True, init=True)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_ == "t":
+                p_.uniform_(2e-3, 2e-2)
+            elif n_ != "g":
+                p_.add_(0.05 * p_.abs().mean() * torch.randn_like(p_))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x = cva.utils.synthetic_clip((2, 1, 48, 64), seed=9)
+    y = x + torch.randn(x.shape, generator=torch.Generator().manual_seed(10)) * 25 / 255
+    b = torch.randn(y.shape, generator=torch.Generator().manual_seed(12))
+    h = 1e-3
+    with loop.precision_scope(precision):
+        outs = net._run(y.cuda(), 25.0, 1, True)
+        outs_b = net._run((y + h * b).cuda(), 25.0, 1, True)
+        s2 = (25.0 / 255.0) ** 2
+        loss = torch.mean((y.cuda() - outs[0]) ** 2) + 2.0 * torch.mean(s2 * b.cuda() * (outs_b[0] - outs[0])) / h
+        loss.backward()
+    sup = [c.detach().cpu() for c in outs[2:]] + [outs[1].detach().cpu()]
+    sup_b = [c.detach().cpu() for c in outs_b[2:]] + [outs_b[1].detach().cpu()]
+    ref_loss, ref = O.mcsure_loss_and_grads(sd, y, b, K=K, P=P, s=1, sigma=25.0, adaptive=True, h=h, supports=sup,
+                                            supports_b=sup_b)
+    assert abs(loss.item() - ref_loss) < 2e-4 * max(1.0, abs(ref_loss))
+    for pname, p_ in net.named_parameters():
+        if pname != "g":
+            check(f"mcsure[{precision}] fused K3 M32 P5 grad {pname} (both supports prescribed)", p_.grad, ref[pname], 1e-4)

@@ -31,6 +31,10 @@ CONFIGS = {
     "s2030-arch": ("2d", dict(K=30, M=169, P=7, s=2, C=1), (64, 1, 256, 256), 25.0, False, 1),
     "cfg3": ("3d", dict(K=20, M=48, P=[5, 5, 5], s=1, C=1), (8, 1, 8, 128, 128), 25.0, False, 1),
     "cfg4": ("2d", dict(K=42, M=64, P=7, s=1, C=3), (8, 3, 256, 256), (1.0, 20.0), True, 1),
+    # the shipped 3-D net (/root/reference/args3dmri.json:3-14): kernel (kD, kH, kW) = (9, 9, 5), stride 2 in all three
+    # directions, crops of 128 x 128, batch 1 (args3dmri.json:24-27 loads 30 frames; 16 = the model's `depth`)
+    "args3dmri": ("3d", dict(K=30, M=169, P=[9, 9, 5], s=2, C=1), (1, 1, 16, 128, 128), 25.0, False, 1),
+    "args3dmri-b8": ("3d", dict(K=30, M=169, P=[9, 9, 5], s=2, C=1), (8, 1, 16, 128, 128), 25.0, False, 1),
     "cfg5": ("gabor", dict(K=30, M=64, P=7, s=1, C=1, order=1, shared=""), (16, 1, 256, 256), 25.0, False, 1),
 }
 

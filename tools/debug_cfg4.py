@@ -23,8 +23,14 @@ x = cva.utils.synthetic_clip(shape, seed=4)
 m = cva.gen_bayer_mask(x)
 sig = torch.tensor([12.0]).reshape(1, 1, 1, 1)
 y = m * (x + torch.randn(shape, generator=torch.Generator().manual_seed(104)) * sig / 255)
-for envs in ({}, {"CDL_MFMA_SYNTHESIS": "0"}, {"CDL_MFMA_WGRAD": "0"}, {"CDL_MFMA_ANALYSIS": "0"}):
-    for k in ("CDL_MFMA_SYNTHESIS", "CDL_MFMA_WGRAD", "CDL_MFMA_ANALYSIS"):
+ref64 = None
+try:                                            # how far the fp32 oracle itself is from an fp64 evaluation
+    sd64 = {k: v.double() for k, v in sd.items()}
+    net._run  # noqa
+except Exception:
+    pass
+for envs in ({}, {"CDL_FUSEDG_PREC": "0"}, {"CDL_FUSEDG_PREC": "2", "CDL_MFMA_WGRAD": "0"}, {"CDL_FUSEDG_PREC": "0", "CDL_MFMA_WGRAD": "0"}):
+    for k in ("CDL_MFMA_SYNTHESIS", "CDL_MFMA_WGRAD", "CDL_MFMA_ANALYSIS", "CDL_FUSEDG_PREC"):
         os.environ.pop(k, None)
     os.environ.update(envs)
     cva._lib.reload_options()
