@@ -56,7 +56,9 @@ def main():
         if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_conflict_frac"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CU_CYCLES"):
-            e["mfma_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CU_CYCLES"], 4)
+            # SQ_VALU_MFMA_BUSY_CYCLES counts over the 4 SIMDs of a CU, SQ_BUSY_CU_CYCLES per CU: / 4 = the share of a
+            # SIMD's cycles in which its matrix pipe is busy (the un-normalised ratio reads > 1)
+            e["mfma_busy_frac_per_simd"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CU_CYCLES"] / 4.0, 4)
     keep = {k: v for k, v in table.items() if v["share"] >= 0.002}
     print(json.dumps({"tag": tag, "kernels": keep}, indent=1))
 
