@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--M", type=int, default=64)
     ap.add_argument("--P", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary s2030-architecture measurement")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--precision", default="split3", choices=["split3", "bf16"],
                     help="fused-kernel arithmetic: split-bf16 x3 (fp32-grade, default) or plain bf16")
@@ -393,6 +394,37 @@ def run_rank(args):
             "kernel_timing": "fat kernels: HIP events around every launch inside 3 further steps (in-step); "
                              "thin kernels and isolated_ms: back-to-back re-launches of one kernel",
         }
+        if world == 1 and not args.no_secondary:
+            # secondary line (not the metric): the SHIPPED 2-D architecture -- CDLNet-s2030: K=30 M=169 P=7 stride 2
+            # (/root/reference/trained_nets/CDLNet-s2030/args.json:2-9) -- on the same batch, forward and forward + backward
+            # (loss.backward(), no optimiser), through the strip kernel (cdl_strip.hip); roofline fractions from
+            # BASELINE.md section 3's bytes per pixel (2 K M b / s^2 + thin)
+            try:
+                note("secondary: shipped s2030 architecture")
+                with contextlib.redirect_stdout(sys.stderr):
+                    torch.manual_seed(1)
+                    net2 = cva.CDLNet(K=30, M=169, P=7, s=2, C=1, t0=5e-3, adaptive=True, init=True).to(dev)
+                with torch.no_grad():
+                    f2 = sorted(event_ms(lambda: net2(y_inf, 25.0), 1) for _ in range(5))[2]
+
+                def fb2():
+                    for p_ in net2.parameters():
+                        p_.grad = None
+                    xh, _ = net2(y_inf, 25.0)
+                    torch.mean((x - xh) ** 2).backward()
+                b2 = sorted(event_ms(fb2, 1) for _ in range(3))[1]
+                bpp = 2 * 30 * 169 * 4 / 4 + 31 * 4
+                out["secondary_s2030_arch"] = {
+                    "model": "CDLNet K=30 M=169 P=7 s=2 C=1", "batch": f"{B}x1x{S}x{S}",
+                    "fused": bool(cva.ops.fusedg_supported(cva.ops.Geometry.make(B, 1, 169, (S, S), (7, 7), (3, 3), 2))),
+                    "fwd_ms": round(f2, 3), "fwd_mpix_s": round(B * S * S / f2 / 1e3, 2),
+                    "fwd_frac_of_hbm_roofline": round(B * S * S / (f2 * 1e-3) * bpp / (HBM_PEAK_GBS * 1e9), 4),
+                    "fwdbwd_ms": round(b2, 3), "fwdbwd_mpix_s": round(B * S * S / b2 / 1e3, 2),
+                    "fwdbwd_frac_of_hbm_roofline": round(B * S * S / (b2 * 1e-3) * 3 * bpp / (HBM_PEAK_GBS * 1e9), 4)}
+                del net2
+                torch.cuda.empty_cache()
+            except Exception as exc:                      # never let the secondary line cost the metric
+                out["secondary_s2030_arch"] = {"error": repr(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             nb = min(args.cpu_batch, B)
             xs = x_cpu[:nb]

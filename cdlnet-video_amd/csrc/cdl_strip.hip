@@ -538,37 +538,54 @@ __global__ __launch_bounds__(NTS) void k_strip(SParams p)
 // out[n,0,Y,X] = (mask ? mask : 1) * alpha * (sum of the patches covering (Y, X)) - (sub ? sub : 0).
 // (Y + HALO) = S * nrow + f, (X + HALO) = S * m + e: parity plane (f, e), half-resolution position (nrow, m); covered by
 // the segment / strip that contains it and, near their upper / left border, by the one before.  Fixed order.
-template <int P, int S>
+// V pixels per thread (V = 4 when W % 4 == 0: 16-byte thin accesses; every pixel still sums its own <= 4 patch values in
+// the same order, so both forms are bit-identical).
+template <int P, int S, int V>
 __global__ __launch_bounds__(256) void k_assemble_s(const float *__restrict__ patches, const float *__restrict__ mask,
                                                     const float *__restrict__ sub, float alpha, float *__restrict__ out,
                                                     int N, int H, int W, int nsx, int nsy, int SEG, int prows)
 {
     constexpr int HALO = P / 2, PXW = Strip<P, S>::PXW;
-    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, n = blockIdx.z;
-    if (X >= W) return;
+    const int X0 = (blockIdx.x * 256 + threadIdx.x) * V, Y = blockIdx.y, n = blockIdx.z;
+    if (X0 >= W) return;
     const int f = (Y + HALO) % S, nrow = (Y + HALO) / S;
-    const int e = (X + HALO) % S, m = (X + HALO) / S;
-    const int If = (P - f + S - 1) / S, Je = (P - e + S - 1) / S;       // taps in this parity class
-    const int sy_hi = min(nsy - 1, nrow / SEG), sx_hi = min(nsx - 1, m / 32);
+    const int If = (P - f + S - 1) / S;                                  // taps in this row-parity class
+    const int sy_hi = min(nsy - 1, nrow / SEG);
     const bool y_lo = sy_hi > 0 && nrow - (sy_hi - 1) * SEG < SEG + If - 1;
-    const bool x_lo = sx_hi > 0 && m - (sx_hi - 1) * 32 < 32 + Je - 1;
     const size_t pplane = (size_t)prows * PXW;
-    auto at = [&](int sy, int sx) {
-        const size_t item = ((size_t)n * nsy + sy) * nsx + sx;
-        return patches[(item * (S * S) + (size_t)(f * S + e)) * pplane + (size_t)(nrow - sy * SEG) * PXW + (m - sx * 32)];
-    };
-    float sum = 0.0f;
-    if (y_lo) {
-        if (x_lo) sum += at(sy_hi - 1, sx_hi - 1);
-        sum += at(sy_hi - 1, sx_hi);
+    float v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int X = X0 + k;
+        const int e = (X + HALO) % S, m = (X + HALO) / S;
+        const int Je = (P - e + S - 1) / S;
+        const int sx_hi = min(nsx - 1, m / 32);
+        const bool x_lo = sx_hi > 0 && m - (sx_hi - 1) * 32 < 32 + Je - 1;
+        auto at = [&](int sy, int sx) {
+            const size_t item = ((size_t)n * nsy + sy) * nsx + sx;
+            return patches[(item * (S * S) + (size_t)(f * S + e)) * pplane + (size_t)(nrow - sy * SEG) * PXW + (m - sx * 32)];
+        };
+        float sum = 0.0f;
+        if (y_lo) {
+            if (x_lo) sum += at(sy_hi - 1, sx_hi - 1);
+            sum += at(sy_hi - 1, sx_hi);
+        }
+        if (x_lo) sum += at(sy_hi, sx_hi - 1);
+        sum += at(sy_hi, sx_hi);
+        v[k] = alpha * sum;
     }
-    if (x_lo) sum += at(sy_hi, sx_hi - 1);
-    sum += at(sy_hi, sx_hi);
-    const size_t i = ((size_t)n * H + Y) * W + X;
-    float v = alpha * sum;
-    if (mask) v *= mask[i];
-    if (sub) v -= sub[i];
-    out[i] = v;
+    const size_t i = ((size_t)n * H + Y) * W + X0;
+    if (V == 4) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (mask) { const float4 mm = *reinterpret_cast<const float4 *>(mask + i); o.x *= mm.x; o.y *= mm.y; o.z *= mm.z; o.w *= mm.w; }
+        if (sub) { const float4 sv = *reinterpret_cast<const float4 *>(sub + i); o.x -= sv.x; o.y -= sv.y; o.z -= sv.z; o.w -= sv.w; }
+        *reinterpret_cast<float4 *>(out + i) = o;
+    } else {
+        float o = v[0];
+        if (mask) o *= mask[i];
+        if (sub) o -= sub[i];
+        out[i] = o;
+    }
 }
 
 template <int P, int S, int MTP, int MODE, bool MAPPED>
@@ -710,8 +727,13 @@ size_t cdl_strip_rsc_floats(const cdl_geom *g, const cdl_strip_plan &pl)
 int cdl_strip_assemble(const cdl_geom *g, const cdl_strip_plan &pl, const float *patches, const float *mask,
                        const float *sub, float alpha, float *out, hipStream_t st)
 {
-    dim3 grid((unsigned)((g->W + 255) / 256), (unsigned)g->H, (unsigned)g->N);
-#define CDL_ASM_S(P_, S_) k_assemble_s<P_, S_><<<grid, 256, 0, st>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, pl.nsx, pl.nsy, pl.SEG, pl.prows)
+    const bool v4 = (g->W & 3) == 0 && !cdl_opts().scalar_assemble;      // (CDL_SCALAR_ASSEMBLE=1: the scalar form, for tests)
+    dim3 grid((unsigned)(((v4 ? g->W / 4 : g->W) + 255) / 256), (unsigned)g->H, (unsigned)g->N);
+#define CDL_ASM_S(P_, S_)                                                                                                   \
+    do {                                                                                                                    \
+        if (v4) k_assemble_s<P_, S_, 4><<<grid, 256, 0, st>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, pl.nsx, pl.nsy, pl.SEG, pl.prows); \
+        else k_assemble_s<P_, S_, 1><<<grid, 256, 0, st>>>(patches, mask, sub, alpha, out, g->N, g->H, g->W, pl.nsx, pl.nsy, pl.SEG, pl.prows);    \
+    } while (0)
     if (pl.S == 2) { if (pl.P == 3) CDL_ASM_S(3, 2); else if (pl.P == 5) CDL_ASM_S(5, 2); else CDL_ASM_S(7, 2); }
     else { if (pl.P == 3) CDL_ASM_S(3, 1); else if (pl.P == 5) CDL_ASM_S(5, 1); else CDL_ASM_S(7, 1); }
 #undef CDL_ASM_S

@@ -258,10 +258,13 @@ _SCRATCH = {}
 
 
 def _scratch(device, n):
-    """One grow-only scratch buffer per device for kernels that need transient partial sums."""
-    buf = _SCRATCH.get(device)
+    """One grow-only scratch buffer per (device, STREAM) for kernels that need transient partial sums: launches on one
+    stream are ordered, so they may share it; two streams each get their own (a single per-device buffer would be a
+    silent race between concurrent streams)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < n:
-        buf = _SCRATCH[device] = torch.empty(n, device=device, dtype=torch.float32)
+        buf = _SCRATCH[key] = torch.empty(n, device=device, dtype=torch.float32)
     return buf
 
 
@@ -270,8 +273,8 @@ def wgrad(g: Geometry, z, x, alpha=1.0, gate=None):
     dw = torch.empty(g.filter_shape(), device=z.device, dtype=torch.float32)
     gs = g.c_struct()
     n = int(_lib.lib().cdl_wgrad_workspace_floats(ctypes.byref(gs)))
-    key = (z.device, n)
-    ws = _WGRAD_WS.get(key)                       # one scratch buffer per (device, size), reused
+    key = (z.device, torch.cuda.current_stream(z.device).cuda_stream, n)
+    ws = _WGRAD_WS.get(key)                       # one scratch buffer per (device, stream, size), reused
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(max(n, 1), device=z.device, dtype=torch.float32)
     rc = _lib.lib().cdl_wgrad(ctypes.byref(gs), _ptr(z), _ptr(gate), _ptr(x), float(alpha), _ptr(dw),
@@ -288,7 +291,7 @@ def wgrad_pair(g: Geometry, z0, x0, alpha0, z1, x1, alpha1):
     dw1 = torch.empty_like(dw0)
     gs = g.c_struct()
     n = int(_lib.lib().cdl_wgrad_workspace_floats(ctypes.byref(gs)))
-    key = (z0.device, n)
+    key = (z0.device, torch.cuda.current_stream(z0.device).cuda_stream, n)
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(max(n, 1), device=z0.device, dtype=torch.float32)

@@ -242,3 +242,21 @@ def test_s2030_net_routes_through_the_strip_kernel_and_is_sample_independent():
             assert torch.equal(xn, xhat[n:n + 1]) and torch.equal(zn, z[n:n + 1]), n
     assert torch.isfinite(xhat).all()
     log(f"s2030-arch K6 batch 5x96x128: PSNR noisy {cva.psnr(x, y):.2f} -> {cva.psnr(x, xhat.cpu()):.2f}")
+
+
+def test_strip_assemble_vector_form_is_bit_identical(hip_env):
+    """k_assemble_s<.., 4> (W % 4 == 0: 4 pixels per thread, 16-byte thin accesses) against the scalar form
+    (CDL_SCALAR_ASSEMBLE=1): same sums in the same order, stride 1 and 2."""
+    import cdlnet_video_amd as cva
+    o = cva.ops
+    for N, M, P, s, sp in ((3, 169, 7, 2, (72, 136)), (2, 100, 7, 1, (40, 68)), (2, 64, 5, 2, (40, 72))):
+        g = make_geom(N, M, P, s, sp)
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        patches = torch.randn(o.fusedg_patches(g, "cuda").shape, device="cuda", generator=gen)
+        yp = torch.randn(g.image_shape(), device="cuda", generator=gen)
+        mask = (torch.rand(g.image_shape(), device="cuda", generator=gen) < 0.5).float()
+        outs = []
+        for scalar in ("0", "1"):
+            hip_env("CDL_SCALAR_ASSEMBLE", scalar)
+            outs.append((o.fusedg_assemble(g, patches, mask, yp, 1.0), o.fusedg_assemble(g, patches, None, None, -1.0)))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (N, M, P, s, sp)
