@@ -80,7 +80,7 @@ SIGNATURES = {
     "cdl_fused2d_forward": [_G, _I] + [_P] * 11 + [_I, _P],
     "cdl_fused2d_backward": [_G, _I] + [_P] * 20 + [_I, _P],
     "cdl_fusedg_supported": [_G],
-    "cdl_fusedg_code_layout": [_G],
+    "cdl_fusedg_code_layout": [_G, _I],
     "cdl_fusedg_set_timeline": [_P],
     "cdl_fusedg_prep": [_G, _P, _P, _P, _P],
     "cdl_fusedg_iter_fwd": [_G, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],

@@ -1054,14 +1054,15 @@ size_t cdl_fusedg_map_words(const cdl_geom *g)
     return rt.kind == 1 ? rt.sp.map_words : (size_t)g->N * 4 * g->D * g->H * g->W;
 }
 
-/* The layout the sweeps should keep z[0..K-2] and the du buffers in: CDL_LAY_RSC for the strip kernel's shapes when the
- * matrix-core filter-gradient kernel takes the geometry, CDL_LAY_NCHW otherwise; cdl_fusedg_code_floats: floats of one
+/* The layout the sweeps should keep z[0..K-2] and the du buffers in: CDL_LAY_RSC for the strip kernel's shapes (training:
+ * when the matrix-core filter-gradient kernel takes the geometry), CDL_LAY_NCHW otherwise; cdl_fusedg_code_floats: floats of one
  * code tensor in that layout. */
-int cdl_fusedg_code_layout(const cdl_geom *g)
+int cdl_fusedg_code_layout(const cdl_geom *g, int training)
 {
     Route rt;
     if (!route_for(g, &rt) || rt.kind == 0) return CDL_LAY_NCHW;
-    return cdl_mfma_wgrad_takes(g) ? CDL_LAY_RSC : CDL_LAY_NCHW;
+    // a forward-only sweep has no filter gradients to feed: the strip kernels' own layout always
+    return (!training || cdl_mfma_wgrad_takes(g)) ? CDL_LAY_RSC : CDL_LAY_NCHW;
 }
 
 size_t cdl_fusedg_code_floats(const cdl_geom *g, int layout)

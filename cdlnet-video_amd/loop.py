@@ -273,7 +273,7 @@ class UnrolledISTA(torch.autograd.Function):
         ctx.fusedg = BACKEND == "auto" and not ctx.fused and ops.fusedg_supported(g)
         if ctx.fusedg:
             # codes handed to the caller (forward_generator) must be (N,M,..); otherwise they stay in the sweeps' layout
-            ctx.layout = "nchw" if want_codes else ops.fusedg_code_layout(g)
+            ctx.layout = "nchw" if want_codes else ops.fusedg_code_layout(g, training=keep)
             xp, z, codes, resid, maps = _forward_fusedg(g, yp, mask_p, tau, A, B, keep or want_codes, keep, ctx.layout)
         elif ctx.fused:
             # codes handed to the caller (forward_generator) must be (N,M,H,W); otherwise they stay internal

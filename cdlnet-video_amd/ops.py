@@ -930,11 +930,12 @@ def fusedg_dtau_reduce(g: Geometry, dtau_partial, c, dt_k):
     _lib.check(rc, "cdl_fusedg_dtau_reduce")
 
 
-def fusedg_code_layout(g: Geometry) -> str:
-    """Layout the fused generic sweeps keep their internal codes in: "rsc" for the strip kernel's shapes when the
-    matrix-core filter-gradient kernel takes the geometry, else "nchw" (cdl_fusedg_code_layout)."""
+def fusedg_code_layout(g: Geometry, training=True) -> str:
+    """Layout the fused generic sweeps keep their internal codes in: "rsc" for the strip kernels' shapes (with
+    `training`: when the matrix-core filter-gradient kernel takes the geometry, since its VALU fallbacks read the
+    reference layout only), else "nchw" (cdl_fusedg_code_layout)."""
     gs = g.c_struct()
-    return "rsc" if int(_lib.lib().cdl_fusedg_code_layout(ctypes.byref(gs))) == LAYOUT["rsc"] else "nchw"
+    return "rsc" if int(_lib.lib().cdl_fusedg_code_layout(ctypes.byref(gs), int(bool(training)))) == LAYOUT["rsc"] else "nchw"
 
 
 def _fusedg_code_buffers(g: Geometry, layout, device, count):

@@ -391,11 +391,12 @@ size_t cdl_fusedg_frag_bytes(const cdl_geom *g);           /* bytes of one prepa
 size_t cdl_fusedg_patch_floats(const cdl_geom *g);
 size_t cdl_fusedg_tiles(const cdl_geom *g);                /* workgroup tiles (= dtau_partial rows) per launch */
 size_t cdl_fusedg_map_words(const cdl_geom *g);
-/* Layout for the codes that stay inside a sweep (z[0..K-2], the du buffers): CDL_LAY_RSC where the strip kernel and the
- * matrix-core filter-gradient kernel both take the geometry, CDL_LAY_NCHW otherwise; floats of one code tensor in a
+/* Layout for the codes that stay inside a sweep (z[0..K-2], the du buffers): CDL_LAY_RSC where a strip kernel takes the
+ * geometry and -- when a reverse sweep will follow (training != 0) -- the matrix-core filter-gradient kernel does too,
+ * CDL_LAY_NCHW otherwise; floats of one code tensor in a
  * layout.  cdl_fusedg_forward / _backward take it as CDL_LAYOUT_IN(layout) in `precision`; the single-stage entry points
  * take CDL_LAYOUT_IN (zin / base) and CDL_LAYOUT_OUT (zout / du_out). */
-int cdl_fusedg_code_layout(const cdl_geom *g);
+int cdl_fusedg_code_layout(const cdl_geom *g, int training);
 size_t cdl_fusedg_code_floats(const cdl_geom *g, int layout);
 int cdl_fusedg_prep(const cdl_geom *g, const float *wA, const float *wB, void *frags, void *stream);
 int cdl_fusedg_iter_fwd(const cdl_geom *g, const float *r, const float *zin /*nullable*/, const float *tau /*N,M*/,
