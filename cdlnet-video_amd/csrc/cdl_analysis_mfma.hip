@@ -1,5 +1,5 @@
 // Analysis (correlation with the filter bank) on the matrix cores for the shapes the fused 2-D kernel does not
-// take: any C, 2-D / 3-D, stride 1 / 2, odd square planes up to 9 x 9 (reference F.conv2d / F.conv3d at
+// take: any C, 2-D / 3-D, stride 1 / 2, odd square planes up to 9 x 9 and the 9 x 5 planes of the 3-D MRI net (reference F.conv2d / F.conv3d at
 // model/net.py:85,87,200,205 and their use in the reverse sweep), with cdl_analysis' epilogues:
 //     acc  = alpha * sum_k W[m][k] X[k(px)]            k = (c, kd, ki, kj) in the filter's own memory order
 //     base = zin ? (gate ? (gate != 0 ? zin : 0) : zin) : 0
@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ALX = 32, ALY = 8;          // output-pixel tile: 8 rows of 32 pixels, one row per wave
 constexpr int ANT = 64 * ALY;
 constexpr int TPW = 4;                    // tiles (along x) per workgroup: the weight fragments are loaded once for them
+constexpr size_t LDS_MAX = 152 * 1024;    // dynamic LDS one workgroup may ask for (160 KB per CU)
 
 // filters (M, K) with K = C*Pd*Ph*Pw -> A fragments frag[(R*KS + ks)*2 + hl][lane]: lane (row m = 32R + (lane&31),
 // h = lane>>5) holds taps k = 16ks + 8h + i (zero beyond M or K)
@@ -308,8 +309,9 @@ struct Plan {
 
 bool plan_for(const cdl_geom *g, Plan *p)
 {
-    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->sw != g->sh || (g->sw != 1 && g->sw != 2)) return false;
     if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->Ph != g->Pw && !(g->Ph == 9 && g->Pw == 5)) return false;      // rectangular planes: the shipped 9 x 9 x 5 net
     if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     p->MT = (g->M + 31) / 32;
@@ -320,16 +322,23 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->tilesX = (Wz + ALX - 1) / ALX;
     p->tilesY = (Hz + ALY - 1) / ALY;
     p->groups = (size_t)g->N * Dz * p->tilesY * ((p->tilesX + TPW - 1) / TPW);
-    p->MTW = p->MT <= 2 ? p->MT : 2;                       // 32-channel tiles per workgroup
-    p->ngy = (p->MT + p->MTW - 1) / p->MTW;                // channel groups (grid.y)
-    p->frag_uint4 = (size_t)p->ngy * p->MTW * p->KS * 2 * 64;   // padded to whole groups
     const size_t XH = (size_t)(ALY - 1) * g->sh + g->Ph, XW = (size_t)(ALX - 1) * g->sw + g->Pw;
     const size_t PS = ((XH * XW + 7) / 8) * 8;
     size_t planes = (size_t)g->C * g->Pd * PS * 2 * 2;
     if (planes < 32 * ALX * ALY * 4) planes = 32 * ALX * ALY * 4;          // the epilogue staging reuses them
-    p->lds = (size_t)p->MTW * p->KS * 2 * 64 * 16 + (size_t)p->KS * 16 * 4 + planes + (size_t)32 * p->MTW * 4;
-    if (p->lds > 96 * 1024) return false;
-    if (p->groups < 96 || p->groups >= ((size_t)1 << 31)) return false;    // small launches: the VALU kernels do better
+    // 32-channel tiles per workgroup: two where planes and fragments fit 96 KB (two workgroups per CU); one, with the
+    // whole CU's LDS behind it, for the deep 3-D filters (K = 9*9*5 = 405 taps over 9 planes: 53 + 56 KB)
+    for (p->MTW = p->MT <= 2 ? p->MT : 2; ; p->MTW = 1) {
+        p->lds = (size_t)p->MTW * p->KS * 2 * 64 * 16 + (size_t)p->KS * 16 * 4 + planes + (size_t)32 * p->MTW * 4;
+        if (p->lds <= 96 * 1024 || p->MTW == 1) break;
+    }
+    if (p->lds > 96 * 1024 && (p->MTW != 1 || p->lds > LDS_MAX)) return false;
+    p->ngy = (p->MT + p->MTW - 1) / p->MTW;                // channel groups (grid.y)
+    p->frag_uint4 = (size_t)p->ngy * p->MTW * p->KS * 2 * 64;   // padded to whole groups
+    // small launches: the VALU kernels do better -- unless the filter is so deep (K >= 256) that they crawl, where the
+    // channel groups count as workgroups too
+    const size_t wgs = K >= 256 ? p->groups * p->ngy : p->groups;
+    if (wgs < 96 || p->groups >= ((size_t)1 << 31)) return false;
     return true;
 }
 
@@ -338,7 +347,8 @@ int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *fr
                const float *gate, const float *tau, float *out, const cdl_prox_args &px, hipStream_t st,
                const float *zsup, float *dtp)
 {
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX, REV>, 96 * 1024)) return rc;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX, REV>, p.lds > 96 * 1024 ? LDS_MAX : 96 * 1024))
+        return rc;
     k_ana_m<PH, PW, SW, MT, PROX, REV><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
         *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS, zsup, dtp);
     CDL_LAUNCH_CHECK();
@@ -424,10 +434,12 @@ int cdl_mfma_analysis_rev(const cdl_geom *g, const float *x, const float *w, flo
     float *dtp = ws + p.frag_uint4 * 4;
     const int S_ = (g->D / g->sd) * p.tilesY * p.tilesX;
     int rc = CDL_EUNSUPPORTED;
-#define CDL_M(P_, S2_) \
-    if (g->Pw == P_ && g->sw == S2_) rc = launch<P_, P_, S2_>(g, p, x, w, alpha, zin, nullptr, nullptr, out, cdl_prox_args{}, ws, S(stream), zsup, dtp)
-    CDL_M(3, 1); else CDL_M(5, 1); else CDL_M(7, 1); else CDL_M(9, 1);
-    else CDL_M(3, 2); else CDL_M(5, 2); else CDL_M(7, 2); else CDL_M(9, 2);
+#define CDL_M(PH_, P_, S2_) \
+    if (g->Ph == PH_ && g->Pw == P_ && g->sw == S2_) \
+        rc = launch<PH_, P_, S2_>(g, p, x, w, alpha, zin, nullptr, nullptr, out, cdl_prox_args{}, ws, S(stream), zsup, dtp)
+    CDL_M(3, 3, 1); else CDL_M(5, 5, 1); else CDL_M(7, 7, 1); else CDL_M(9, 9, 1);
+    else CDL_M(3, 3, 2); else CDL_M(5, 5, 2); else CDL_M(7, 7, 2); else CDL_M(9, 9, 2);
+    else CDL_M(9, 5, 1); else CDL_M(9, 5, 2);
 #undef CDL_M
     if (rc) return rc;
     k_ana_tau_final<<<g->M, 512, 0, S(stream)>>>(dtp, c, dt0, dt1, g->N, g->M, S_);
@@ -449,10 +461,12 @@ int cdl_mfma_analysis(const cdl_geom *g, const float *x, const float *w, float a
     Plan p;
     if (!plan_for(g, &p) || !ws || ws_floats < p.frag_uint4 * 4) return CDL_EUNSUPPORTED;
     if ((reinterpret_cast<size_t>(ws) & 15) != 0) return CDL_EUNSUPPORTED;
-#define CDL_M(P_, S_) \
-    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, x, w, alpha, zin, gate, tau, out, px, ws, S(stream))
-    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
-    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#define CDL_M(PH_, P_, S_) \
+    if (g->Ph == PH_ && g->Pw == P_ && g->sw == S_) \
+        return launch<PH_, P_, S_>(g, p, x, w, alpha, zin, gate, tau, out, px, ws, S(stream))
+    CDL_M(3, 3, 1); CDL_M(5, 5, 1); CDL_M(7, 7, 1); CDL_M(9, 9, 1);
+    CDL_M(3, 3, 2); CDL_M(5, 5, 2); CDL_M(7, 7, 2); CDL_M(9, 9, 2);
+    CDL_M(9, 5, 1); CDL_M(9, 5, 2);
 #undef CDL_M
     return CDL_EUNSUPPORTED;
 }

@@ -1,5 +1,5 @@
 // Synthesis (transposed convolution) on the matrix cores for the shapes the fused 2-D kernel does not take:
-// any C, 2-D or 3-D, stride 1 or 2, odd square filter planes up to 9 x 9 (reference F.conv_transpose2d/3d at
+// any C, 2-D or 3-D, stride 1 or 2, odd square filter planes up to 9 x 9 and 9 x 5 (reference F.conv_transpose2d/3d at
 // model/net.py:87,90,205,210).
 //
 //   col[tap][px] = sum_m W^T[tap][m] * z[m][px]          one GEMM per (image channel c, depth tap kd):
@@ -379,8 +379,9 @@ struct Plan {
 
 bool plan_for(const cdl_geom *g, Plan *p)
 {
-    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->sw != g->sh || (g->sw != 1 && g->sw != 2)) return false;
     if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->Ph != g->Pw && !(g->Ph == 9 && g->Pw == 5)) return false;      // rectangular planes: the shipped 9 x 9 x 5 net
     if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     p->tilesX = (Wz + TCX - 1) / TCX;
@@ -452,10 +453,12 @@ int cdl_mfma_synthesis(const cdl_geom *g, const float *z, const float *gate, con
     Plan p;
     if (!plan_for(g, &p) || !ws || ws_floats < p.frag_uint4 * 4 + p.patch_floats) return CDL_EUNSUPPORTED;
     if ((reinterpret_cast<size_t>(ws) & 15) != 0) return CDL_EUNSUPPORTED;
-#define CDL_M(P_, S_)                                                                                  \
-    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, z, gate, w, alpha, mask, sub, out, ws, S(stream))
-    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
-    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#define CDL_M(PH_, P_, S_)                                                  \
+    if (g->Ph == PH_ && g->Pw == P_ && g->sw == S_)                         \
+        return launch<PH_, P_, S_>(g, p, z, gate, w, alpha, mask, sub, out, ws, S(stream))
+    CDL_M(3, 3, 1); CDL_M(5, 5, 1); CDL_M(7, 7, 1); CDL_M(9, 9, 1);
+    CDL_M(3, 3, 2); CDL_M(5, 5, 2); CDL_M(7, 7, 2); CDL_M(9, 9, 2);
+    CDL_M(9, 5, 1); CDL_M(9, 5, 2);
 #undef CDL_M
     return CDL_EUNSUPPORTED;
 }

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                                              const float *__restrict__ gate, const float *__restrict__ x0,
                                              float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP CDL_DBG_COMMA(int dbg),
                                              int ntiles, int tpw, const float *__restrict__ F1,
-                                             const float *__restrict__ x1, int rsc)
+                                             const float *__restrict__ x1, int rsc, int gspan)
 {
+    // blockIdx.z: the (c, kd) groups [z gspan, (z + 1) gspan) -- the group passes of a tile are independent (each re-reads the
+    // fat operand and owns its partial rows), so a launch with few tiles spreads them over workgroups.
     // blockIdx.y = 1: the second (fat, thin) operand pair of a paired launch (dA_k and dB_k of one iteration), its
     // partial banks behind the first pair's
     const float *__restrict__ F = blockIdx.y ? F1 : F0;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         }
     };
 
-    for (int g0 = 0; g0 < G; g0 += NG) {
+    const int g_end = min(G, (int)(blockIdx.z + 1) * gspan);
+    for (int g0 = blockIdx.z * gspan; g0 < g_end; g0 += NG) {
         f32x16 acc[NG][RT][CT];
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
@@ -469,8 +472,9 @@ struct Plan {
 
 bool plan_for(const cdl_geom *g, Plan *p)
 {
-    if (g->sw != g->sh || g->Ph != g->Pw || (g->sw != 1 && g->sw != 2)) return false;
+    if (g->sw != g->sh || (g->sw != 1 && g->sw != 2)) return false;
     if (g->Pw != 3 && g->Pw != 5 && g->Pw != 7 && g->Pw != 9) return false;
+    if (g->Ph != g->Pw && !(g->Ph == 9 && g->Pw == 5)) return false;      // rectangular planes: the shipped 9 x 9 x 5 net
     if (g->pw != g->Pw / 2 || g->ph != g->Ph / 2) return false;
     const int Dz = g->D / g->sd, Hz = g->H / g->sh, Wz = g->W / g->sw;
     const int MT = (g->M + 31) / 32;
@@ -501,7 +505,10 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->lds = p->ng * plane;
     if (p->lds < 8 * 16 * 64 * 4) p->lds = 8 * 16 * 64 * 4;  // the cross-wave reduction buffer reuses it
     if (p->lds > LDS_MAX) return false;
-    if (p->tiles < 64 || p->tiles >= ((size_t)1 << 31)) return false;   // too few workgroups: the VALU kernels do better
+    // too few workgroups: the VALU kernels do better -- except under deep filters (C Pd Ph Pw >= 256 taps, the 9 x 9 x 5
+    // net at batch 1: 16 tiles), where k_wgrad_l takes 0.76 ms a launch
+    const size_t min_tiles = (size_t)G * g->Ph * g->Pw >= 256 ? 8 : 64;
+    if (p->tiles < min_tiles || p->tiles >= ((size_t)1 << 31)) return false;
     if (p->part_floats > ((size_t)1 << 27)) return false;               // 512 MiB of partials: not worth it
     return true;
 }
@@ -511,9 +518,16 @@ int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gat
               hipStream_t st, const float *F1, const float *x1, int rsc)
 {
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_wgm<PH, PW, SW, NG, CT>, LDS_MAX)) return rc;
-    k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1), GNT, p.lds, st>>>(
+    // group passes over workgroups while the launch would leave CUs idle (gspan a multiple of NG)
+    const int G = g->C * g->Pd, passes = (G + NG - 1) / NG;
+    const size_t wgs = p.blocks * (F1 ? 2 : 1), cus = (size_t)cdl_cu_count();
+    int gz = 1;
+    while (gz < passes && wgs * (gz + 1) <= cus) ++gz;
+    const int gspan = ((passes + gz - 1) / gz) * NG;
+    gz = (G + gspan - 1) / gspan;
+    k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1, (unsigned)gz), GNT, p.lds, st>>>(
         *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP CDL_DBG_COMMA(cdl_opts().fused_debug & (1024 | 2048 | 4096)), (int)p.tiles,
-        p.tpw, F1, x1, rsc);
+        p.tpw, F1, x1, rsc, gspan);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -564,10 +578,12 @@ static int wgrad_entry(const cdl_geom *g, const float *F, const float *gate, con
     p.tpw = (int)((jobs * p.tiles + cus - 1) / cus);        // workgroup = the number of rounds a tile-per-workgroup grid takes
     p.blocks = (p.tiles + p.tpw - 1) / p.tpw;
     if (ws_floats < jobs * p.blocks * ((size_t)g->C * g->Pd * p.TP * p.MP)) return CDL_EUNSUPPORTED;
-#define CDL_M(P_, S_) \
-    if (g->Pw == P_ && g->sw == S_) return launch<P_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream), F1, x1, alpha1, dw1, rsc)
-    CDL_M(3, 1); CDL_M(5, 1); CDL_M(7, 1); CDL_M(9, 1);
-    CDL_M(3, 2); CDL_M(5, 2); CDL_M(7, 2); CDL_M(9, 2);
+#define CDL_M(PH_, P_, S_)                                   \
+    if (g->Ph == PH_ && g->Pw == P_ && g->sw == S_)          \
+        return launch<PH_, P_, S_>(g, p, F, gate, x, alpha, dw, ws, S(stream), F1, x1, alpha1, dw1, rsc)
+    CDL_M(3, 3, 1); CDL_M(5, 5, 1); CDL_M(7, 7, 1); CDL_M(9, 9, 1);
+    CDL_M(3, 3, 2); CDL_M(5, 5, 2); CDL_M(7, 7, 2); CDL_M(9, 9, 2);
+    CDL_M(9, 5, 1); CDL_M(9, 5, 2);
 #undef CDL_M
     return CDL_EUNSUPPORTED;
 }

@@ -41,6 +41,11 @@ SHAPES = [
     (2, 16, 32, (3, 17, 33), (3, 3, 3), 1),
     (1, 24, 40, (20, 45), (3, 3), 1),
     (1, 20, 70, (2, 9, 34), (1, 5, 5), 1),
+    # the args3dmri.json filter (9, 9, 5) on the matrix cores: 405 taps over 9 depth planes -- one channel tile per analysis
+    # workgroup with > 96 KB of LDS, rectangular 9 x 5 planes in all three kernels, the filter gradient's (c, kd) group passes
+    # spread over workgroups (24 / 16 tiles); stride 2 as shipped, and stride 1
+    (6, 1, 40, (8, 32, 72), (9, 9, 5), 2),
+    (4, 1, 33, (4, 24, 40), (9, 9, 5), 1),
 ]
 
 
@@ -306,7 +311,7 @@ def test_synthesis_assemble_vector_form_is_bit_identical(hip_env):
 
 
 @pytest.mark.parametrize("path", ["mfma", "valu"])
-@pytest.mark.parametrize("N,C,M,sp,P,s", [SHAPES[1], SHAPES[3], SHAPES[5], SHAPES[10], SHAPES[11], SHAPES[12], SHAPES[14]])
+@pytest.mark.parametrize("N,C,M,sp,P,s", [SHAPES[1], SHAPES[3], SHAPES[5], SHAPES[10], SHAPES[11], SHAPES[12], SHAPES[14], SHAPES[18]])
 def test_reverse_analysis_step(N, C, M, sp, P, s, path, hip_env):
     """cdl_analysis_rev_ws: out = [zsup != 0] (zin + alpha A x) with the threshold gradients of `out` -- fused into the
     matrix-core analysis epilogue where that kernel exists, composed (analysis, then gate + threshold pass) elsewhere --
