@@ -65,6 +65,7 @@ SIGNATURES = {
     "cdl_gabor_filters": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_gabor_filters_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cdl_options_reload": [],
+    "cdl_set_exact_fp32": [_I],
     "cdl_gabor_filter_banks": [_I, _P, _P, _P, _P, _IP, _P, _I, _I, _I, _I, _P],
     "cdl_gabor_filter_banks_bwd": [_I, _P, _P, _P, _P, _IP, _P, _P, _I, _I, _I, _I, _P],
     "cdl_fused2d_supported": [_G],

@@ -118,18 +118,47 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
         if (tx >= tilesX) break;                           // uniform
         const int ybase = ty * ALY * SW - g.ph, xbase = tx * ALX * SW - g.pw;
         __syncthreads();                                   // previous tile's readers are done (and the tables are in)
-        for (int p = 0; p < NP; ++p) {
-            const int kd = p % g.Pd, c = p / g.Pd;
-            const int d = zd * g.sd - g.pd + kd;
-            const bool dok = d >= 0 && d < g.D;
-            const float *xplane = x + (((size_t)n * g.C + c) * g.D + (dok ? d : 0)) * g.H * g.W;
-            for (int i = threadIdx.x; i < XH * XW; i += ANT) {
-                const int col = i % XW, row = i / XW;
-                const int yy = ybase + row, xx = xbase + col;
-                const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
-                const __bf16 hh = (__bf16)v;
-                xh[p * PS + i] = hh;
-                xl[p * PS + i] = (__bf16)(v - (float)hh);
+        // PB planes x ITS elements per thread are loaded (clamped addresses, no branches) before any of them is converted:
+        // one plane element at a time was a dependent global-load latency per element -- 27 in a row under the 9 x 9 x 5
+        // filter, most of that launch's 84 us
+        constexpr int ITS = (XH * XW + ANT - 1) / ANT, PB = ITS <= 2 ? 4 : 3;
+        int eoff[ITS];
+        bool eok[ITS];
+#pragma unroll
+        for (int u = 0; u < ITS; ++u) {
+            const int i = threadIdx.x + u * ANT;
+            const int col = i % XW, row = i / XW;
+            const int yy = ybase + row, xx = xbase + col;
+            eok[u] = i < XH * XW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            eoff[u] = min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1);
+        }
+        for (int p0 = 0; p0 < NP; p0 += PB) {
+            float v[PB][ITS];
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                const int p = min(p0 + pp, NP - 1);
+                const int kd = p % g.Pd, c = p / g.Pd;
+                const int d = zd * g.sd - g.pd + kd;
+                const bool dok = p0 + pp < NP && d >= 0 && d < g.D;      // uniform
+                const float *xplane = x + (((size_t)n * g.C + c) * g.D + min(max(d, 0), g.D - 1)) * g.H * g.W;
+#pragma unroll
+                for (int u = 0; u < ITS; ++u) {
+                    const float t = xplane[eoff[u]];
+                    v[pp][u] = (dok && eok[u]) ? t : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                if (p0 + pp >= NP) break;                                // uniform
+#pragma unroll
+                for (int u = 0; u < ITS; ++u) {
+                    const int i = threadIdx.x + u * ANT;
+                    if (i < XH * XW) {
+                        const __bf16 hh = (__bf16)v[pp][u];
+                        xh[(p0 + pp) * PS + i] = hh;
+                        xl[(p0 + pp) * PS + i] = (__bf16)(v[pp][u] - (float)hh);
+                    }
+                }
             }
         }
         __syncthreads();

@@ -117,6 +117,7 @@ struct cdl_options {
     int fused_debug, dense_debug;                                // -DCDL_ABLATE builds only (always 0 in the product)
 };
 const cdl_options &cdl_opts();                                   // snapshot of the environment, read once
+bool cdl_exact_fp32();                                           // this host thread asked for the fp32 VALU tier (cdl_set_exact_fp32)
 int cdl_current_device();
 int cdl_cu_count();                                              // compute units of the CURRENT device
 int cdl_ensure_dynamic_lds(const void *kernel, int bytes);       // per (device, kernel): keep the dynamic-LDS limit >= bytes

@@ -696,13 +696,13 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
 // enough; CDL_MFMA_ANALYSIS=0 selects the VALU kernels (read per call)
 static bool mfma_analysis_enabled(const cdl_geom *g)
 {
-    return cdl_opts().mfma_analysis != 0;
+    return cdl_opts().mfma_analysis != 0 && !cdl_exact_fp32();
 }
 
 // the dense many-channel tier (cdl_dense_mfma.hip; C >= 16 on both sides, unit stride); CDL_MFMA_DENSE=0 disables
 static bool mfma_dense_enabled()
 {
-    return cdl_opts().mfma_dense != 0;
+    return cdl_opts().mfma_dense != 0 && !cdl_exact_fp32();
 }
 
 size_t cdl_analysis_workspace_floats(const cdl_geom *g)
@@ -813,7 +813,7 @@ static int analysis_impl(const cdl_geom *g, const float *x, const float *w, floa
 // selects the fp32 VALU kernels (read per call, so one process can compare both)
 static bool mfma_synthesis_enabled()
 {
-    return cdl_opts().mfma_synthesis != 0;
+    return cdl_opts().mfma_synthesis != 0 && !cdl_exact_fp32();
 }
 
 size_t cdl_synthesis_workspace_floats(const cdl_geom *g)
@@ -872,7 +872,7 @@ int cdl_synthesis_ws(const cdl_geom *g, const float *z, const float *gate, const
 // matrix-core filter gradients are the default wherever they have a kernel; CDL_MFMA_WGRAD=0 selects the VALU ones
 static bool mfma_wgrad_enabled()
 {
-    return cdl_opts().mfma_wgrad != 0;
+    return cdl_opts().mfma_wgrad != 0 && !cdl_exact_fp32();
 }
 
 size_t cdl_wgrad_workspace_floats(const cdl_geom *g)

@@ -52,6 +52,8 @@ const cdl_options *load_options()
     return o;
 }
 
+thread_local int t_exact_fp32 = 0;          // cdl_set_exact_fp32: per host thread, off the snapshot
+
 constexpr int MAX_DEV = 64;
 std::atomic<int> g_cus[MAX_DEV];
 std::mutex g_attr_mutex;
@@ -71,6 +73,15 @@ const cdl_options &cdl_opts()
         }
     }
     return *o;
+}
+
+bool cdl_exact_fp32() { return t_exact_fp32 != 0; }
+
+extern "C" int cdl_set_exact_fp32(int on)
+{
+    const int prev = t_exact_fp32;
+    t_exact_fp32 = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int cdl_options_reload(void)

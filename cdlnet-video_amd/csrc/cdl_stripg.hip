@@ -116,7 +116,6 @@ __global__ __launch_bounds__(NTS) void k_stripg(GSParams p)
     }
     __syncthreads();
     auto afrag = [&](int f) { return __builtin_bit_cast(bf16x8, wa[f * 64 + lane]); };
-    auto bfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wb[f * 64 + lane]); };
 
     const int HW = p.H * p.W, DHW = p.D * HW;
     const int up_addr = ((lane & 31) + 32) * 4;

@@ -283,13 +283,28 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 const int d = zd * g.sd - g.pd + kd;
                 const bool dok = grp < G && d >= 0 && d < g.D;  // uniform; a plane outside the image is a zero tile
                 const float *xplane = x + (((size_t)n * g.C + (dok ? c : 0)) * g.D + (dok ? d : 0)) * g.H * g.W;
-                for (int i = threadIdx.x; i < XH * XW; i += GNT) {
-                    const int col = i % XW, row = i / XW;
-                    const int yy = ybase + row, xx = xbase + col;
-                    const float v = (dok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? xplane[(size_t)yy * g.W + xx] : 0.0f;
-                    const __bf16 hh = (__bf16)v;
-                    xh[gi * XE + i] = hh;
-                    xl[gi * XE + i] = (__bf16)(v - (float)hh);
+                // SBW loads (clamped addresses, no branches) in flight per thread before any is converted: one element at a
+                // time was a dependent global-load latency each, 18 per plane under the 9 x 5 filter
+                constexpr int SBW = 6;
+                for (int i0 = threadIdx.x; i0 < XH * XW; i0 += GNT * SBW) {
+                    float v[SBW];
+#pragma unroll
+                    for (int u = 0; u < SBW; ++u) {
+                        const int i = i0 + u * GNT;
+                        const int col = i % XW, row = i / XW;
+                        const int yy = ybase + row, xx = xbase + col;
+                        const float t = xplane[(size_t)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+                        v[u] = (dok && i < XH * XW && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? t : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < SBW; ++u) {
+                        const int i = i0 + u * GNT;
+                        if (i < XH * XW) {
+                            const __bf16 hh = (__bf16)v[u];
+                            xh[gi * XE + i] = hh;
+                            xl[gi * XE + i] = (__bf16)(v[u] - (float)hh);
+                        }
+                    }
                 }
             }
         }
@@ -502,6 +517,9 @@ bool plan_for(const cdl_geom *g, Plan *p)
                                     : ((XH * XW + 7) / 8) * 8 * 2 * 2;                    // hi + lo bf16 planes of one group
     if (G >= 5 && RT == 1 && 5 * plane <= LDS_MAX) p->ng = 5;
     else if (G >= 3 && RT <= 2 && 3 * plane <= LDS_MAX) p->ng = 3;
+    // a launch that leaves most CUs idle even with its group passes spread (launch_ct: blockIdx.z) does better with one group
+    // per pass: three times the workgroups, a third of the accumulators each (no spills at two channel tiles per wave)
+    if (p->ng == 3 && p->tiles * 2 * ((G + 2) / 3) * 2 <= (size_t)cdl_cu_count()) p->ng = 1;
     p->lds = p->ng * plane;
     if (p->lds < 8 * 16 * 64 * 4) p->lds = 8 * 16 * 64 * 4;  // the cross-wave reduction buffer reuses it
     if (p->lds > LDS_MAX) return false;

@@ -22,8 +22,11 @@ from . import ops
 # has one (cdl_fused2d_supported) and the shape-generic kernels otherwise; "generic" forces the latter.
 # PRECISION applies to the fused 2-D kernels only: "split3" (split-bf16 with three products per multiply: fp32-grade, the
 # default), "split4" (all four products: exact fp32 products -- what an objective that differences two forward passes
-# needs, see precision_scope / train.mcsure_loss) or "bf16".
+# needs, see precision_scope / train.mcsure_loss) or "bf16".  "fp32" is a different tier altogether: no fused kernels and no
+# matrix cores -- the three-launch iteration on the fp32 VALU kernels (plain fp32 FMAs, several times slower), for the cases
+# where 16-17 significant bits per MFMA operand are not enough (cancelling filter gradients: DESIGN.md section 6).
 BACKEND = "auto"
+ARITHMETIC = tuple(ops.PRECISION) + ("fp32",)
 PRECISION = "split3"
 # How the fused sweeps store the codes that never leave them (z_1..z_{K-1}, du_k): "blocked" (pixel-blocked
 # fp32: same values as "nchw", wider memory accesses; the default), "nchw", or "blocked_bf16" (opt-in bf16
@@ -40,17 +43,18 @@ def set_backend(name):
 
 def set_precision(name):
     global PRECISION
-    if name not in ops.PRECISION:
+    if name not in ARITHMETIC:
         raise ValueError(name)
     PRECISION = name
 
 
 class precision_scope:
     """`with precision_scope("split4"): ...` -- the fused 2-D sweeps started inside run in that arithmetic; their reverse
-    sweeps use the arithmetic of their forward whenever backward() is called."""
+    sweeps use the arithmetic of their forward whenever backward() is called.  `precision_scope("fp32")`: every network
+    call started inside (any net of this package) runs, forward and backward, on the fp32 VALU kernels."""
 
     def __init__(self, name):
-        if name not in ops.PRECISION:
+        if name not in ARITHMETIC:
             raise ValueError(name)
         self.name = name
 
@@ -239,6 +243,24 @@ def _backward_fused_stepwise(g, K, yp, mask_p, c, A, B, codes, resid, g_xp, g_z,
     return dA, dB
 
 
+def _arithmetic_aware(cls):
+    """Class decorator of the autograd Functions below: a call made under PRECISION == "fp32" runs its forward AND (whenever it
+    happens) its backward with the generic entry points pinned to the fp32 VALU kernels (ops.exact_fp32)."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx.exact = PRECISION == "fp32"
+        with ops.exact_fp32(ctx.exact):
+            return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with ops.exact_fp32(ctx.exact):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def _no_data_gradients(ctx):
     """The reverse sweeps produce parameter (and neighbour-code) gradients only.  The reference's loop is
     differentiable in the observation, the mask and sigma as well (no caller in the reference uses that); asking for
@@ -249,6 +271,7 @@ def _no_data_gradients(ctx):
                                       f"(the HIP reverse sweep returns parameter gradients only); detach() it")
 
 
+@_arithmetic_aware
 class UnrolledISTA(torch.autograd.Function):
     """(y, mask, c, t, A_0..A_{K-1}, B_0..B_{K-1}) -> (xhat, z_K[, z_1..z_{K-1}])."""
 
@@ -269,8 +292,9 @@ class UnrolledISTA(torch.autograd.Function):
         _no_data_gradients(ctx)
         keep = any(ctx.needs_input_grad)          # all False under torch.no_grad()
         want_codes = cfg.get("all_codes", False)
-        ctx.fused = BACKEND == "auto" and ops.fused_supported(g)
-        ctx.fusedg = BACKEND == "auto" and not ctx.fused and ops.fusedg_supported(g)
+        auto = BACKEND == "auto" and not ctx.exact     # "fp32": the fused kernels are matrix-core kernels
+        ctx.fused = auto and ops.fused_supported(g)
+        ctx.fusedg = auto and not ctx.fused and ops.fusedg_supported(g)
         if ctx.fusedg:
             # codes handed to the caller (forward_generator) must be (N,M,..); otherwise they stay in the sweeps' layout
             ctx.layout = "nchw" if want_codes else ops.fusedg_code_layout(g, training=keep)
@@ -366,6 +390,7 @@ def _forward_csr_stepwise(g, yp, mask_p, lam, gam1, gam2, zp, za, A, B, keep):
     return xp, z, us, codes, resid
 
 
+@_arithmetic_aware
 class TemporalISTA(torch.autograd.Function):
     """(y, mask, c, z_prev, z_after|None, t, g1, g2|None, A.., B..) -> (xhat, z_K); gradients for the
     neighbour codes, the three threshold families and both filter banks."""
@@ -434,6 +459,7 @@ class TemporalISTA(torch.autograd.Function):
 # CDLNetVideo(residual=True) (reference model/net.py:199-212): a ResidualBlock
 # rewrites the code after every iteration, so the sweep is a chain of per-iteration autograd nodes -- one ISTA
 # iteration (the launches of _forward/_backward_generic_stepwise for one k), one block, ..., the synthesis.
+@_arithmetic_aware
 class _ISTAIteration(torch.autograd.Function):
     """(z_k | None, t_k (2,M..), A_k, B_k) -> z_{k+1} = ST(z_k - A_k(mask B_k z_k - yp), tau_k)."""
 
@@ -469,6 +495,7 @@ class _ISTAIteration(torch.autograd.Function):
         return gzin, dt_k, dA, dB, None, None, None, None
 
 
+@_arithmetic_aware
 class ResidualBlockFn(torch.autograd.Function):
     """(x, w1, w2) -> relu(conv2(relu(conv1 x)) + x)  (net.py:113-120)."""
 
@@ -488,6 +515,7 @@ class ResidualBlockFn(torch.autograd.Function):
         return dx, dw1, dw2
 
 
+@_arithmetic_aware
 class _Dictionary(torch.autograd.Function):
     """(z_K, B_0) -> xhat = post_process(D z_K)."""
 

@@ -524,6 +524,24 @@ def gabor_filter_banks_bwd(params, dws, P, transposes):
 
 # ------------------------------------------------------------------------------------------ fused MFMA path
 PRECISION = {"split3": 0, "bf16": 1, "split4": 2}
+
+
+class exact_fp32:
+    """`with exact_fp32(): ...` -- the shape-generic entry points called from this thread inside the block stay on the fp32
+    VALU kernels (cdl_set_exact_fp32, include/cdlnet_hip.h); `exact_fp32(False)` is a no-op block."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            self.prev = _lib.lib().cdl_set_exact_fp32(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.lib().cdl_set_exact_fp32(self.prev)
+        return False
 # layouts of the fat tensors that stay inside a fused sweep (include/cdlnet_hip.h, CDL_LAY_*): "nchw" is the
 # reference's layout, "blocked" the pixel-blocked fp32 layout (same values, 16-byte accesses, the default),
 # "blocked_bf16" opt-in bf16 STORAGE of the codes (half the bytes; outside the 1e-5 parity gate)

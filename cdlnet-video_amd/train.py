@@ -88,7 +88,9 @@ def mcsure_loss(net, obsrv, xhat, sigma, mask=1, h=1e-3, generator=None, b=None)
     bits): per-step gradients agree with fp32 autograd to ~1e-4 (tests/test_gpu_nets.py), and over several Adam steps
     weights whose SURE gradient is below that noise drift apart.  `with loop.precision_scope(
     "split4")` adds the lo * lo products on the fused 2-D path; measured, it does not change that (the operand
-    truncation, not the dropped product, is the floor), so it is not selected here."""
+    truncation, not the dropped product, is the floor), so it is not selected here.  `with loop.precision_scope("fp32")`
+    around the training step runs both passes and their backward on the fp32 VALU kernels (6e-6 instead of 7e-5 per step,
+    several times slower); the caller chooses."""
     if b is None:
         dev = generator.device if generator is not None else obsrv.device
         b = torch.randn(obsrv.shape, device=dev, dtype=obsrv.dtype, generator=generator).to(obsrv.device)

@@ -55,6 +55,14 @@ const char *cdl_version(void);
  * immutable snapshot; tests and tools that flip a variable mid-process call this afterwards). */
 int cdl_options_reload(void);
 
+/* Arithmetic of the shape-generic entry points (cdl_analysis*, cdl_synthesis*, cdl_wgrad*, cdl_ista_* sweeps) called from
+ * THIS host thread afterwards: on != 0 keeps them on the fp32 VALU kernels (plain fp32 FMAs: ~3e-6 of an fp64 evaluation even
+ * where sums cancel), on == 0 (the default) lets them use the matrix cores (split-bf16 operands: 16-17 significant bits, which
+ * a cancelling filter gradient amplifies -- DESIGN.md section 6).  Returns the previous setting.  The fused entry points
+ * (cdl_fused2d_*, cdl_fusedg_*) are matrix-core kernels by construction and are not affected: a caller that wants fp32
+ * end to end composes the generic ones (the Python host side does: loop.precision_scope("fp32")). */
+int cdl_set_exact_fp32(int on);
+
 /* ---- boundary of the loop: model/utils.py:5-22 (pre_process), :70-87 (pre_process_3d) -------
  * mean[n] = sum(y[n]) / (mask ? sum(mask[n]) : numel);  yp = reflect_pad(mask * (y - mean));
  * mask_p = reflect_pad(mask).  pads = {d_lo, d_hi, h_lo, h_hi, w_lo, w_hi} (floor/ceil split,

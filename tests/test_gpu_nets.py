@@ -223,13 +223,14 @@ def test_mcsure_objective_vs_oracle():
             check(f"mcsure grad {pname}", p.grad, ref_grads[pname], 1e-3)
 
 
-@pytest.mark.parametrize("precision", ["split3", "split4"])
+@pytest.mark.parametrize("precision", ["split3", "split4", "fp32"])
 def test_mcsure_gradients_on_the_fused_path_with_both_supports_prescribed(precision):
     """the per-step MC-SURE gradient of the fused 2-D path (the f12 trajectory's geometry: K=3, M=32,
     P=5) against autograd of the oracle with the supports of BOTH forward passes prescribed (no support flip can enter;
     what remains is arithmetic, multiplied by 1/h = 1e3).  Gate 1e-4 of each tensor's maximum (measured: 6.7e-5 / 5.6e-5).  "split4" (all four bf16
     products) is measured beside the default: the two-term operand split (16-17 significant bits), not the dropped
-    lo * lo product, is the floor, so it buys nothing."""
+    lo * lo product, is the floor, so it buys nothing.  "fp32": the same objective on the fp32 VALU
+    tier (no fused kernel, no matrix cores)."""
     import cdlnet_video_amd as cva
     from cdlnet_video_amd import loop
     torch.manual_seed(31)
@@ -260,4 +261,43 @@ def test_mcsure_gradients_on_the_fused_path_with_both_supports_prescribed(precis
     assert abs(loss.item() - ref_loss) < 2e-4 * max(1.0, abs(ref_loss))
     for pname, p_ in net.named_parameters():
         if pname != "g":
-            check(f"mcsure[{precision}] fused K3 M32 P5 grad {pname} (both supports prescribed)", p_.grad, ref[pname], 1e-4)
+            check(f"mcsure[{precision}] K3 M32 P5 grad {pname} (both supports prescribed)", p_.grad, ref[pname],
+                  2e-5 if precision == "fp32" else 1e-4)          # measured: fp32 6.3e-6, split3 6.7e-5, split4 5.6e-5
+
+
+def test_fp32_scope_is_the_valu_tier_forward_and_backward(hip_env):
+    """`loop.precision_scope("fp32")` = no fused kernel and no matrix cores: bit-identical (output and every gradient) to
+    the generic backend with all four CDL_MFMA_* switches off, and within the 1e-5 gate of the default fused path.  The
+    backward runs OUTSIDE the scope: the arithmetic is the forward's."""
+    import cdlnet_video_amd as cva
+    from cdlnet_video_amd import loop
+    torch.manual_seed(77)
+    net = cva.CDLNet(K=4, M=64, P=7, s=1, C=1, t0=5e-3, adaptive=True, init=True).cuda()
+    x = cva.utils.synthetic_clip((2, 1, 64, 96), seed=5).cuda()
+    y = x + torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(6)) * 25 / 255
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        xhat, _ = net(y, 25.0)
+        return xhat, torch.mean((x - xhat) ** 2)
+
+    xd, ld = run()                                        # default: fused matrix-core sweep
+    ld.backward()
+    with loop.precision_scope("fp32"):
+        xa, la = run()
+    la.backward()                                         # outside the scope
+    ga = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for name in ("CDL_MFMA_ANALYSIS", "CDL_MFMA_SYNTHESIS", "CDL_MFMA_WGRAD", "CDL_MFMA_DENSE"):
+        hip_env(name, "0")
+    loop.set_backend("generic")
+    try:
+        xb, lb = run()
+        lb.backward()
+    finally:
+        loop.set_backend("auto")
+    assert torch.equal(xa, xb)
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(ga[n], p.grad), n
+    assert not torch.equal(xa, xd)
+    check("fp32 tier vs fused sweep", xa, xd.cpu(), 1e-5)

@@ -136,3 +136,21 @@ def test_fit_replays_the_reference_mcsure_trajectory(tmp_path):
     worst = _replay("sure", tmp_path, 321, False, psnr_tol=0.05, lr=1e-3, epochs=2, clip_grad=5e-2, noise_std=25,
                     val_freq=1, save_freq=1, backtrack_thresh=1, mcsure=True)
     assert all(e == e and e < 1.0 for e in worst.values()), worst
+
+
+def test_fit_replays_the_reference_mcsure_trajectory_on_the_fp32_tier(tmp_path):
+    """The same replay with every network call on the fp32 VALU kernels (`loop.precision_scope("fp32")`): the finite
+    difference now multiplies fp32 rounding only (per-step gradient 6e-6 of autograd with both supports prescribed,
+    tests/test_gpu_nets.py).  Measured: the weights end 2-3x closer to the reference's (thresholds 1.5e-1 instead of 3e-1
+    of max |t|, filters <= 3e-2 instead of 1e-1) but are still not pinned: what is left is not arithmetic precision but the
+    objective -- two fp32 evaluations that differ in the last bit shrink a few code elements to the other side of their
+    threshold, and (net(y + h b) - net(y)) / h turns every such flip into a jump of 1e3 x that element.  Any two fp32
+    implementations of this loop (this one and the CPU reference included) disagree that way; logs, learning rate and
+    PSNR trajectory are gated as above, the weights are reported."""
+    from cdlnet_video_amd import loop
+    from gpu_util import log
+    with loop.precision_scope("fp32"):
+        worst = _replay("sure", tmp_path, 321, False, psnr_tol=0.05, lr=1e-3, epochs=2, clip_grad=5e-2, noise_std=25,
+                        val_freq=1, save_freq=1, backtrack_thresh=1, mcsure=True)
+    log(f"f12 sure replay on the fp32 tier: worst weight deviations {worst}")
+    assert all(e == e and e < 1.0 for e in worst.values()), worst
