@@ -23,7 +23,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int ALX = 32, ALY = 8;          // output-pixel tile: 8 rows of 32 pixels, one row per wave
 constexpr int ANT = 64 * ALY;
-constexpr int TPW = 4;                    // tiles (along x) per workgroup: the weight fragments are loaded once for them
+constexpr int TPW = 4;                    // tiles (along x) per workgroup (the weight fragments are loaded once for them) in launches that
+                                          // fill the chip anyway; fewer when the workgroups would not (Plan::tpw)
 constexpr size_t LDS_MAX = 152 * 1024;    // dynamic LDS one workgroup may ask for (160 KB per CU)
 
 // filters (M, K) with K = C*Pd*Ph*Pw -> A fragments frag[(R*KS + ks)*2 + hl][lane]: lane (row m = 32R + (lane&31),
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
                                                const float *__restrict__ zin, const float *__restrict__ gate,
                                                const float *__restrict__ tau, float *__restrict__ out,
                                                cdl_prox_args px, int tilesX, int tilesY, int KS,
-                                               const float *__restrict__ zsup, float *__restrict__ dtp)
+                                               const float *__restrict__ zsup, float *__restrict__ dtp, int tpw)
 {
     constexpr int XH = (ALY - 1) * SW + PH, XW = (ALX - 1) * SW + PW;
     constexpr int PS = ((XH * XW + 7) / 8) * 8;            // elements per plane
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     }
 
     int b = blockIdx.x;
-    const int txg = b % ((tilesX + TPW - 1) / TPW); b /= (tilesX + TPW - 1) / TPW;
+    const int txg = b % ((tilesX + tpw - 1) / tpw); b /= (tilesX + tpw - 1) / tpw;
     const int ty = b % tilesY; b /= tilesY;
     const int zd = b % Dz, n = b / Dz;
     // thresholds of this workgroup's channels (one sample, MT channel tiles): read once into LDS -- the epilogue read
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
     const size_t slab = (size_t)Dz * Hz * Wz;
     const int pixbase = (wv * SW) * XW + l32 * SW;
 
-    for (int tt = 0; tt < TPW; ++tt) {
-        const int tx = txg * TPW + tt;
+    for (int tt = 0; tt < tpw; ++tt) {
+        const int tx = txg * tpw + tt;
         if (tx >= tilesX) break;                           // uniform
         const int ybase = ty * ALY * SW - g.ph, xbase = tx * ALX * SW - g.pw;
         __syncthreads();                                   // previous tile's readers are done (and the tables are in)
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(ANT) void k_ana_m(cdl_geom g, const float *__restri
 }
 
 struct Plan {
+    int tpw;                               // tiles along x per workgroup
     int tilesX, tilesY, MT, KS, MTW, ngy;
     size_t groups, frag_uint4, lds;
 };
@@ -350,6 +352,7 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->KS = (K + 15) / 16;
     p->tilesX = (Wz + ALX - 1) / ALX;
     p->tilesY = (Hz + ALY - 1) / ALY;
+    p->tpw = TPW;
     p->groups = (size_t)g->N * Dz * p->tilesY * ((p->tilesX + TPW - 1) / TPW);
     const size_t XH = (size_t)(ALY - 1) * g->sh + g->Ph, XW = (size_t)(ALX - 1) * g->sw + g->Pw;
     const size_t PS = ((XH * XW + 7) / 8) * 8;
@@ -366,8 +369,15 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->frag_uint4 = (size_t)p->ngy * p->MTW * p->KS * 2 * 64;   // padded to whole groups
     // small launches: the VALU kernels do better -- unless the filter is so deep (K >= 256) that they crawl, where the
     // channel groups count as workgroups too
-    const size_t wgs = K >= 256 ? p->groups * p->ngy : p->groups;
-    if (wgs < 96 || p->groups >= ((size_t)1 << 31)) return false;
+    // M > 64 (three or more channel tiles, channel groups on grid.y): the VALU kernels are poor there too, so a launch that
+    // would leave CUs idle takes one tile per workgroup (single frames of the M = 169 nets: 48 -> 192 workgroups) and
+    // counts every workgroup
+    if (p->MT >= 3 && p->groups * p->ngy < (size_t)cdl_cu_count()) {
+        p->tpw = 1;
+        p->groups = (size_t)g->N * Dz * p->tilesY * p->tilesX;
+    }
+    const size_t wgs = (K >= 256 || p->MT >= 3) ? p->groups * p->ngy : p->groups;
+    if (wgs < (p->MT >= 3 ? 48 : 96) || p->groups >= ((size_t)1 << 31)) return false;
     return true;
 }
 
@@ -379,7 +389,7 @@ int launch_mtp(const cdl_geom *g, const Plan &p, const float *x, const uint4 *fr
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_ana_m<PH, PW, SW, MT, PROX, REV>, p.lds > 96 * 1024 ? LDS_MAX : 96 * 1024))
         return rc;
     k_ana_m<PH, PW, SW, MT, PROX, REV><<<dim3((unsigned)p.groups, (unsigned)p.ngy), ANT, p.lds, st>>>(
-        *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS, zsup, dtp);
+        *g, x, frags, alpha, zin, gate, tau, out, px, p.tilesX, p.tilesY, p.KS, zsup, dtp, p.tpw);
     CDL_LAUNCH_CHECK();
     return 0;
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                                              const float *__restrict__ gate, const float *__restrict__ x0,
                                              float *__restrict__ part0, int tilesX, int tilesY, int nct, int MP CDL_DBG_COMMA(int dbg),
                                              int ntiles, int tpw, const float *__restrict__ F1,
-                                             const float *__restrict__ x1, int rsc, int gspan)
+                                             const float *__restrict__ x1, int rsc, int gspan, int rs)
 {
     // blockIdx.z: the (c, kd) groups [z gspan, (z + 1) gspan) -- the group passes of a tile are independent (each re-reads the
     // fat operand and owns its partial rows), so a launch with few tiles spreads them over workgroups.
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
     const int npx = 8 / nct;                               // pixel parts (waves per channel group)
     const int cg = wv % nct, pp = wv / nct;
     const bool active = pp < npx;                          // 8 % nct waves idle when nct does not divide 8
-    const int kpw = KSTEPS / npx;                          // k-steps per wave
+    const int kpw = KSTEPS / (npx * rs);                   // k-steps per wave (rs: row parts of a tile, see the tile loop)
     const size_t slab = (size_t)Dz * Hz * Wz;
     // rsc != 0: the fat operands are in the strip kernel's row-strip channel-major layout
     // [n][code depth][code row][ceil(Wz/32)][M][32 columns] (include/cdlnet_hip.h, CDL_LAY_RSC): a lane's 8 consecutive pixels are
@@ -190,6 +190,10 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         for (int tl = 0; tl < tpw; ++tl) {
         int b = blockIdx.x * tpw + tl;
         if (b >= ntiles) break;                            // uniform
+        // rs > 1: a tile's k-steps (its 32 code rows) are split over rs consecutive work items -- launches with a handful of
+        // tiles (one 128 x 128 crop of a stride-2 net: 2) reach more CUs; every item has its own partial bank as before
+        const int kpart = b % rs;
+        b /= rs;
         tx = b % tilesX; b /= tilesX;
         ty = b % tilesY; b /= tilesY;
         zd = b % Dz; n = b / Dz;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
                 }
             }
         };
-        const int k0 = pp * kpw, k1 = (pp + 1) * kpw;       // kpw is a power of two >= 16
+        const int k0 = (kpart * npx + pp) * kpw, k1 = k0 + kpw;   // kpw is a power of two >= 8
         const bool pipelined = PREFETCH && active && fast && !CDL_DBG(dbg, 2048);
         if constexpr (PREFETCH) {
             if (pipelined) {
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(GNT) void k_wgm(cdl_geom g, const float *__restrict
         }
         if (active && !pipelined && !CDL_DBG(dbg, 2048)) {
 #pragma unroll 1
-            for (int ks = pp * kpw; ks < (pp + 1) * kpw; ++ks) {
+            for (int ks = k0; ks < k1; ++ks) {
                 const int zy = ks >> 2, zx0 = (ks & 3) * 16 + 8 * h;       // tile-local pixels zx0 .. zx0+7 of row zy
                 const int cy = ty * GLY + zy, cx0 = tx * GLX + zx0;
                 // ---- B: the fat operand, 8 consecutive pixels of this lane's channel(s); shared by all NG groups
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256) void k_wgm_fold(const float *__restrict__ part
 }
 
 struct Plan {
-    int tilesX, tilesY, nct, npx, MP, TP, ng, ct, tpw;
+    int tilesX, tilesY, nct, npx, MP, TP, ng, ct, tpw, rs;
     size_t tiles, blocks, part_floats, lds;
 };
 
@@ -508,8 +512,6 @@ bool plan_for(const cdl_geom *g, Plan *p)
     p->tilesY = (Hz + GLY - 1) / GLY;
     p->tiles = (size_t)g->N * Dz * p->tilesX * p->tilesY;
     p->tpw = 1;
-    p->blocks = p->tiles;                                  // upper bound (the launch groups tiles by the CU count)
-    p->part_floats = p->tiles * g->C * g->Pd * p->TP * p->MP;
     const size_t XH = (size_t)(GLY - 1) * g->sh + g->Ph, XW = (size_t)(GLX - 1) * g->sw + g->Pw;
     p->ng = 1;                                             // groups held at once: registers (NG*RT*CT*16 <= 192) and LDS permitting
     const int G = g->C * g->Pd, RT = p->TP / 32;
@@ -520,12 +522,20 @@ bool plan_for(const cdl_geom *g, Plan *p)
     // a launch that leaves most CUs idle even with its group passes spread (launch_ct: blockIdx.z) does better with one group
     // per pass: three times the workgroups, a third of the accumulators each (no spills at two channel tiles per wave)
     if (p->ng == 3 && p->tiles * 2 * ((G + 2) / 3) * 2 <= (size_t)cdl_cu_count()) p->ng = 1;
+    // row parts per tile (k_wgm): doubled while a paired launch, its group passes spread, would still leave half the CUs idle
+    p->rs = 1;
+    const size_t spread = p->tiles * 2 * ((G + p->ng - 1) / p->ng);
+    while (p->rs < 8 && spread * (p->rs * 2) * 2 <= (size_t)cdl_cu_count() && KSTEPS / (p->npx * p->rs * 2) >= 8) p->rs *= 2;
+    p->blocks = p->tiles * p->rs;                          // upper bound (the launch groups work items by the CU count)
+    p->part_floats = p->blocks * g->C * g->Pd * p->TP * p->MP;
     p->lds = p->ng * plane;
     if (p->lds < 8 * 16 * 64 * 4) p->lds = 8 * 16 * 64 * 4;  // the cross-wave reduction buffer reuses it
     if (p->lds > LDS_MAX) return false;
     // too few workgroups: the VALU kernels do better -- except under deep filters (C Pd Ph Pw >= 256 taps, the 9 x 9 x 5
     // net at batch 1: 16 tiles), where k_wgrad_l takes 0.76 ms a launch
-    const size_t min_tiles = (size_t)G * g->Ph * g->Pw >= 256 ? 8 : 64;
+    // -- and under many channels (M > 64: `k_wgrad_p` takes 85 us for one 128 x 128 crop at M = 169), where the row parts
+    // above spread the few tiles
+    const size_t min_tiles = MT >= 3 ? 2 : (size_t)G * g->Ph * g->Pw >= 256 ? 8 : 64;
     if (p->tiles < min_tiles || p->tiles >= ((size_t)1 << 31)) return false;
     if (p->part_floats > ((size_t)1 << 27)) return false;               // 512 MiB of partials: not worth it
     return true;
@@ -544,8 +554,8 @@ int launch_ct(const cdl_geom *g, const Plan &p, const float *F, const float *gat
     const int gspan = ((passes + gz - 1) / gz) * NG;
     gz = (G + gspan - 1) / gspan;
     k_wgm<PH, PW, SW, NG, CT><<<dim3((unsigned)p.blocks, F1 ? 2 : 1, (unsigned)gz), GNT, p.lds, st>>>(
-        *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP CDL_DBG_COMMA(cdl_opts().fused_debug & (1024 | 2048 | 4096)), (int)p.tiles,
-        p.tpw, F1, x1, rsc, gspan);
+        *g, F, gate, x, ws, p.tilesX, p.tilesY, p.nct, p.MP CDL_DBG_COMMA(cdl_opts().fused_debug & (1024 | 2048 | 4096)), (int)(p.tiles * p.rs),
+        p.tpw, F1, x1, rsc, gspan, p.rs);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -593,8 +603,9 @@ static int wgrad_entry(const cdl_geom *g, const float *F, const float *gate, con
     if (rsc && gate) return CDL_EUNSUPPORTED;
     const size_t jobs = F1 ? 2 : 1;
     const size_t cus = (size_t)cdl_cu_count();              // one workgroup per CU at a time (registers): tiles per
-    p.tpw = (int)((jobs * p.tiles + cus - 1) / cus);        // workgroup = the number of rounds a tile-per-workgroup grid takes
-    p.blocks = (p.tiles + p.tpw - 1) / p.tpw;
+    const size_t items = p.tiles * p.rs;                    // (tile, row part) work items
+    p.tpw = (int)((jobs * items + cus - 1) / cus);          // workgroup = the number of rounds an item-per-workgroup grid takes
+    p.blocks = (items + p.tpw - 1) / p.tpw;
     if (ws_floats < jobs * p.blocks * ((size_t)g->C * g->Pd * p.TP * p.MP)) return CDL_EUNSUPPORTED;
 #define CDL_M(PH_, P_, S_)                                   \
     if (g->Ph == PH_ && g->Pw == P_ && g->sw == S_)          \

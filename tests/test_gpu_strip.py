@@ -122,14 +122,17 @@ def test_strip_backward_stage_vs_generic(N, M, P, s, sp, masked):
         assert torch.equal(du2, du)
 
 
-@pytest.mark.parametrize("kw,shape,masked", [
-    (dict(K=4, M=169, P=7, s=2, C=1), (2, 1, 75, 77), False),      # odd size: stride padding in pre_process
-    (dict(K=3, M=64, P=5, s=2, C=1), (1, 1, 40, 72), True),
-    (dict(K=3, M=100, P=7, s=1, C=1), (1, 1, 33, 70), False),
-    (dict(K=3, M=169, P=7, s=2, C=1), (16, 1, 128, 250), True),    # enough filter-gradient tiles: internal codes in "rsc"
-    (dict(K=3, M=72, P=5, s=1, C=1), (12, 1, 96, 100), False),     # "rsc" at unit stride, ragged last strip
+@pytest.mark.parametrize("kw,shape,masked,want_lay", [
+    # internal code layout: "rsc" wherever the matrix-core filter-gradient kernel takes the shape -- M > 64 from 2 tiles of
+    # 64 x 32 code pixels on (row parts of a tile spread over workgroups), otherwise from 64 tiles on
+    (dict(K=4, M=169, P=7, s=2, C=1), (2, 1, 75, 77), False, "rsc"),      # odd size: stride padding in pre_process; 4 tiles
+    (dict(K=3, M=64, P=5, s=2, C=1), (1, 1, 40, 72), True, "nchw"),
+    (dict(K=3, M=100, P=7, s=1, C=1), (1, 1, 33, 70), False, "rsc"),
+    (dict(K=3, M=169, P=7, s=2, C=1), (16, 1, 128, 250), True, "rsc"),
+    (dict(K=3, M=72, P=5, s=1, C=1), (12, 1, 96, 100), False, "rsc"),     # unit stride, ragged last strip
+    (dict(K=3, M=48, P=7, s=1, C=1), (2, 1, 40, 60), False, "nchw"),      # few tiles, M <= 64: VALU filter gradients
 ])
-def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked):
+def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked, want_lay):
     """Forward: strip sweep vs generic sweep; reverse: both sweeps fed the SAME saved activations (no support flip can
     enter), every gradient to split-bf16 accuracy; and the strip sweep is reproducible bit for bit."""
     import cdlnet_video_amd as cva
@@ -158,7 +161,7 @@ def test_strip_sweeps_equal_generic_on_same_activations(kw, shape, masked):
     A = [m.weight.detach() for m in net.A]
     B = [m.weight.detach() for m in net.B]
     lay = o.fusedg_code_layout(g)                      # "rsc" when the matrix-core filter-gradient kernel takes the shape
-    assert lay == ("rsc" if shape[0] >= 10 else "nchw")
+    assert lay == want_lay
     xp, z, codes, resid, maps = loop._forward_fusedg(g, yp, mask_p, tau, A, B, True, True, lay)
     xpg, zg, codes_g, resid_g, _ = loop._forward_generic(g, yp, mask_p, tau, A, B, True, True)
     tag = f"strip sweep[{lay}] K{K} M{M} P{P} s{s} {shape}"
@@ -235,16 +238,18 @@ def test_s2030_net_routes_through_the_strip_kernel_and_is_sample_independent():
     y, sig = cva.awgn(x, (20, 30), torch.Generator().manual_seed(3))
     g = cva.ops.Geometry.make(5, 1, 169, (96, 128), (7, 7), (3, 3), 2)
     assert cva.ops.fusedg_supported(g) and cva.loop.BACKEND == "auto"
-    # too few filter-gradient tiles for the matrix-core kernel at this size: training keeps the reference layout, a
-    # forward-only sweep (nothing to feed) uses the strip layout regardless
-    assert cva.ops.fusedg_code_layout(g, training=True) == "nchw" and cva.ops.fusedg_code_layout(g, training=False) == "rsc"
+    # the strip layout in both modes: forward-only sweeps always, training sweeps because the matrix-core filter-gradient
+    # kernel takes M = 169 from 2 tiles on (10 here); a one-tile geometry keeps the reference layout for training
+    assert cva.ops.fusedg_code_layout(g, training=True) == "rsc" and cva.ops.fusedg_code_layout(g, training=False) == "rsc"
+    g1 = cva.ops.Geometry.make(1, 1, 169, (64, 128), (7, 7), (3, 3), 2)
+    assert cva.ops.fusedg_code_layout(g1, training=True) == "nchw" and cva.ops.fusedg_code_layout(g1, training=False) == "rsc"
     with torch.no_grad():
         xhat, z = net(y.cuda(), sig.cuda())
         for n in (0, 4):
             xn, zn = net(y[n:n + 1].cuda(), sig[n:n + 1].cuda())
             assert torch.equal(xn, xhat[n:n + 1]) and torch.equal(zn, z[n:n + 1]), n
     assert torch.isfinite(xhat).all()
-    xt, zt = net(y.cuda(), sig.cuda())                    # the training-mode forward (reference layout here): same values
+    xt, zt = net(y.cuda(), sig.cuda())                    # the training-mode forward: same values
     assert torch.equal(xt.detach(), xhat) and torch.equal(zt.detach(), z)
     log(f"s2030-arch K6 batch 5x96x128: PSNR noisy {cva.psnr(x, y):.2f} -> {cva.psnr(x, xhat.cpu()):.2f}")
 
