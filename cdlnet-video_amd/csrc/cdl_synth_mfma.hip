@@ -72,7 +72,7 @@ template <int PH, int PW, int SW, int KSM>
 __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__restrict__ z,
                                                  const float *__restrict__ gate, const uint4 *__restrict__ frags,
                                                  float *__restrict__ patches, int tilesX, int tilesY, int KS, int KCH,
-                                                 int ntiles)
+                                                 int ntiles, int gspan)
 {
     constexpr int T = PH * PW, RT = (T + 31) / 32;
     constexpr int PY = (TCY - 1) * SW + PH, PX = (TCX - 1) * SW + PW;
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(SNT) void k_synth_m(cdl_geom g, const float *__rest
         }
     }
 
-    for (int grp = 0; grp < G; ++grp) {
+    // blockIdx.y: the (c, kd) groups [y gspan, (y + 1) gspan) -- a group's patch is its own, so a launch with fewer tiles than
+    // CUs (one clip of the 3-D nets) spreads them over workgroups
+    const int grp_end = min(G, (int)(blockIdx.y + 1) * gspan);
+    for (int grp = blockIdx.y * gspan; grp < grp_end; ++grp) {
         const int kd = grp % g.Pd;
         const int d = zd * g.sd - g.pd + kd;
         if (d < 0 || d >= g.D) continue;                    // uniform: this depth tap falls outside the image
@@ -418,10 +421,15 @@ int launch(const cdl_geom *g, const Plan &p, const float *z, const float *gate, 
     if (int rc = cdl_ensure_dynamic_lds((const void *)k_synth_m<PH, PW, SW, 4>, 150 * 1024)) return rc;
     const size_t cus = (size_t)cdl_cu_count();
     const unsigned grid_m = (unsigned)(p.tiles < cus ? p.tiles : cus);      // one workgroup per CU (64-108 KB of LDS each)
-    if (p.KS <= 4 && g->C * g->Pd > 1)       // several groups share the code values: keep their fragments in registers
-        k_synth_m<PH, PW, SW, 4><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
+    const int G = g->C * g->Pd;
+    int gy = 1;                                                             // group chunks while CUs would idle
+    while (gy < G && (size_t)grid_m * (gy + 1) <= cus) ++gy;
+    const int gspan = (G + gy - 1) / gy;
+    const dim3 grid_s(grid_m, (unsigned)((G + gspan - 1) / gspan));
+    if (p.KS <= 4 && G > 1)                  // several groups share the code values: keep their fragments in registers
+        k_synth_m<PH, PW, SW, 4><<<grid_s, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles, gspan);
     else
-        k_synth_m<PH, PW, SW, 0><<<grid_m, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles);
+        k_synth_m<PH, PW, SW, 0><<<grid_s, SNT, p.lds, st>>>(*g, z, gate, frags, patches, p.tilesX, p.tilesY, p.KS, p.KCH, (int)p.tiles, gspan);
     CDL_LAUNCH_CHECK();
     const size_t al = reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(mask) | reinterpret_cast<size_t>(sub);
     if ((g->W & 3) == 0 && (al & 15) == 0 && !cdl_opts().scalar_assemble) {     // (CDL_SCALAR_ASSEMBLE=1: the scalar form, for tests)
