@@ -111,6 +111,7 @@ struct cdl_options {
     int no_tiled, no_pipelined_synthesis;                        // CDL_NO_TILED, CDL_NO_PIPELINED_SYNTHESIS
     int fused_snake;                                             // CDL_FUSED_SNAKE=0: no alternating tile direction
     int fused_grid;                                              // CDL_FUSED_GRID=n: fewer persistent workgroups (probes)
+    int fused_da;                                                // CDL_FUSED_DA=0: dA_k by k_wgrad2d instead of inside the reverse stage
     int fusedg_bwd_prec;                                         // CDL_FUSEDG_PREC=0|2: forces the arithmetic of the tile kernel's sweeps (experiments)
     int fusedg_strip;                                            // CDL_FUSEDG_STRIP=1: cdl_stripg.hip instead of the tile kernel k_stage_g
     int scalar_assemble;                                         // CDL_SCALAR_ASSEMBLE=1: the one-pixel-per-thread patch assemble (tests)

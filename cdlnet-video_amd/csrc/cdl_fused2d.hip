@@ -43,7 +43,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int WX = 2, WY = 4;               // waves per workgroup along x / y
+#ifndef CDL_WY
+#define CDL_WY 2
+#endif
+#ifndef CDL_LDS_PAD
+#define CDL_LDS_PAD 0
+#endif
+constexpr int WX = 2, WY = CDL_WY;          // waves per workgroup along x / y
 constexpr int NW = WX * WY;                 // 8 waves
 constexpr int NT = 64 * NW;                 // 512 threads
 constexpr int RB = 8;                       // row blocks (image rows) per wave
@@ -51,7 +57,8 @@ constexpr int TW = 32 * WX, TH = RB * WY;   // 64 x 32 tile
 constexpr int HALO = 3;                     // filters are embedded in a 7 x 7 (padded 8 x 8) tap grid
 constexpr int RTW = TW + 2 * HALO, RTH = TH + 2 * HALO;   // 70 x 38 residual tile / patch
 constexpr int RTC = RTW + 2;                // columns kept in LDS (col 70 is the zero-weight pad tap)
-constexpr int PITCH = 44;                   // bf16 elements per LDS column (88 B: conflict-free b64 reads)
+constexpr int PITCH = WY == 2 ? 28 : 44;    // bf16 elements per LDS column (>= RTH + 2; 56 / 88 B: 14 / 22 dwords between the columns of
+                                            // neighbouring lanes -- conflict-free b64 reads)
 constexpr int COPY = RTC * PITCH;           // elements per shifted copy
 constexpr int LDS_RT = 2 * 4 * COPY * 2;    // bytes: {hi,lo} x 4 row-shifted copies             (50688)
 constexpr int SLAB = RTH * RTW;             // floats per col2im slab
@@ -61,6 +68,17 @@ constexpr int LDS_W = 32 * 64 * 16;         // 32 weight fragments of 1 KB (spli
 constexpr int LDS_TAU = 64 * 4;
 constexpr int LDS_TACC = NW * 64 * 4;
 constexpr int LDS_STAGE = LDS_RT + LDS_RSUM + LDS_W + LDS_TAU + LDS_TACC;
+
+constexpr int GW_TH = 16;                    // tile rows of the filter-gradient kernel
+constexpr int GW_RTH = GW_TH + 2 * HALO;     // 22
+constexpr int TROWS = GW_RTH + 1;            // halo rows + the (never used) i = 7 pad row
+constexpr int TPITCH = 72;                   // bf16 elements per row of a shifted copy (144 B)
+constexpr int TCOPY = TROWS * TPITCH;
+constexpr int WG_THIN_BYTES = 2 * 2 * 4 * TCOPY * 2;      // [op][hl][shift] copies               (52992)
+constexpr int IMG_ELEMS = 32 * 32;           // one [32 px][32 ch] bf16 image (2 KB)
+
+constexpr int LDS_DA_THIN = 2 * 4 * TCOPY * 2;           // reverse stage with dA_k: r_k as [hl][shift] copies   (26496)
+constexpr int LDS_DA = LDS_DA_THIN + NW * 2 * 2 * IMG_ELEMS * 2;   // + [wave][channel tile][hl] transposition images
 
 struct FusedParams {
     const float *r;          // (N,H,W) thin input of the analysis-like half (r_k, yp, q_{k+1} or g_xp)
@@ -78,6 +96,8 @@ struct FusedParams {
                              // 4 no analysis MFMAs, 8 no thin staging, 16 no fat loads; results are wrong
     int N, H, W, tilesX, tilesY;
     int rev;                 // walk the tiles from the last to the first (see "snake order" at the sweeps)
+    const float *r2;         // reverse stage with DA: (N,H,W) thin operand of dA_k = alpha * du_k (x) im2col(r2) (r_k or yp)
+    float *da_partial;       // (gridDim.x, 2, M, 64): per-workgroup partial of dA_k in operator slot 0 (k_wgrad_reduce's layout)
 };
 
 enum { MODE_FWD = 0, MODE_FIRST = 1, MODE_BWD = 2 };
@@ -352,15 +372,20 @@ __device__ __forceinline__ float col2im_row(const float (&rv)[4], int h)
 // MODE_BWD            : zout = [z_{k+1} != 0] * (zin + A-like r),  dtau partials   (reverse sweep);
 //                       support and sign of z_{k+1} come from the 2-bit map, not from the fat tensor
 //   LIN / LOUT: layouts of zin and zout (LAY_*)
-template <int MT, int PREC, int MODE, int LIN, int LOUT>
+//   DA (reverse stage only): the filter gradient dA_k = du_k (x) im2col(r2) rides in the launch -- du_k is transposed per row
+//   block through wave-private LDS images exactly as k_wgrad2d does it, and accumulated in 2 x MT more accumulator tiles
+template <int MT, int PREC, int MODE, int LIN, int LOUT, bool DA = false>
 __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
 {
+    static_assert(!DA || (MODE == MODE_BWD && TH == GW_TH), "dA_k rides in the reverse stage, on k_wgrad2d's 64 x 16 tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *rt = reinterpret_cast<__bf16 *>(smem);                               // [hl][q][col][PITCH]
     float *rsum_all = reinterpret_cast<float *>(smem + LDS_RT);                   // [4][RTH][RTW]
     const uint4 *wl = reinterpret_cast<const uint4 *>(smem + LDS_RT + LDS_RSUM);  // weight fragments
     float *tau_s = reinterpret_cast<float *>(smem + LDS_RT + LDS_RSUM + LDS_W);
     float *tacc_s = tau_s + 64;                                                   // backward: [wave][64]
+    __bf16 *thin2 = reinterpret_cast<__bf16 *>(smem + LDS_STAGE);                 // DA: [hl][s][TCOPY] copies of r2's tile
+    __bf16 *imgs2 = reinterpret_cast<__bf16 *>(smem + LDS_STAGE + LDS_DA_THIN);   // DA: [wave][R][hl][IMG_ELEMS]
 
     constexpr int M = 32 * MT;
     constexpr int FA = MT * 4, FB = 4 * MT;
@@ -421,9 +446,58 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 }
         }
     };
+    // DA: the tile of r2 under this tile (22 x 70 with the halo), as 4 column-shifted bf16 hi/lo copies (k_wgrad2d's
+    // format: every 8-pixel window of an im2col row 8-byte aligned); loaded a tile ahead like the thin input
+    constexpr int NSTG2 = DA ? (GW_RTH * RTW + NT - 1) / NT : 1;
+    float stg2[NSTG2];
+    auto stage2_load = [&](int t) {
+        int bid = p.rev ? numTiles - 1 - t : t;
+        const int txi = bid % p.tilesX; bid /= p.tilesX;
+        const int tyi = bid % p.tilesY;
+        const int n = bid / p.tilesY;
+        const float *timg = p.r2 + (t < numTiles ? (size_t)n * HW : 0);      // (past the last tile: nothing is read)
+#pragma unroll
+        for (int k = 0; k < NSTG2; ++k) {
+            const int i = tid + k * NT;
+            const int yy = i / RTW, xx = i % RTW;
+            const int gy = tyi * TH - HALO + yy, gx = txi * TW - HALO + xx;
+            const bool ok = i < GW_RTH * RTW && t < numTiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float v = timg[ok ? (size_t)gy * p.W + gx : 0];
+            stg2[k] = ok ? v : 0.0f;
+        }
+    };
+    auto stage2_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < NSTG2; ++k) {
+            const int i = tid + k * NT;
+            if (i >= GW_RTH * RTW) continue;
+            const int yy = i / RTW, xx = i % RTW;
+            const __bf16 hh = (__bf16)stg2[k];
+            const __bf16 ll = (__bf16)(stg2[k] - (float)hh);
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft)
+                if (xx - sft >= 0) {
+                    thin2[(0 * 4 + sft) * TCOPY + yy * TPITCH + xx - sft] = hh;
+                    if (PREC != 1) thin2[(1 * 4 + sft) * TCOPY + yy * TPITCH + xx - sft] = ll;
+                }
+        }
+    };
+    f32x16 dacc[DA ? MT : 1][2];              // DA: dA_k[channel tile][tap tile], over every tile of this workgroup
+    if constexpr (DA) {
+#pragma unroll
+        for (int R = 0; R < MT; ++R)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dacc[R][tt][v] = 0.0f;
+        // pad elements of the copies are read (into ignored tap columns) and must stay finite
+        for (int i = tid; i < LDS_DA_THIN / 16; i += NT) reinterpret_cast<uint4 *>(thin2)[i] = make_uint4(0, 0, 0, 0);
+        stage2_load(blockIdx.x);
+    }
     stage_load(blockIdx.x);
     __syncthreads();                                        // zero pass done before the first fill
     stage_store();
+    if constexpr (DA) stage2_store();
 
     // fragment offsets inside the LDS weight area
     constexpr int OFF_AH = 0;
@@ -645,6 +719,80 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
                 map_n[HW + (size_t)y * p.W + x] = wg;
             }
         }
+        if constexpr (DA) {
+            // dA_k += du_k (x) im2col(r2) for this row block: k_wgrad2d's product with the fat operand taken from the
+            // accumulator registers (register v of tile R = channel 32R + 8(v>>2) + 4h + (v&3) of pixel column c: the
+            // layout its loads have) instead of from memory
+            __bf16 *wimg = imgs2 + (size_t)wid * (MT * 2) * IMG_ELEMS;
+#pragma unroll
+            for (int R = 0; R < MT; ++R)
+#pragma unroll
+                for (int qv = 0; qv < 4; ++qv) {
+                    bf16x4 hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = acc[R][4 * qv + e];
+                        const __bf16 hh = (__bf16)val;
+                        hi4[e] = hh;
+                        lo4[e] = (__bf16)(val - (float)hh);
+                    }
+                    const int slot = (2 * qv + h) ^ ((c >> 1) & 7);      // 8-byte slot of channels 8qv+4h..+3
+                    __bf16 *dst = wimg + (size_t)(R * 2) * IMG_ELEMS + c * 32 + slot * 4;
+                    *reinterpret_cast<bf16x4 *>(dst) = hi4;
+                    if (PREC != 1 && LOUT != LAY_BLK16) *reinterpret_cast<bf16x4 *>(dst + IMG_ELEMS) = lo4;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 Bh[2], Bl[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int tap = 32 * tt + c, ti = tap >> 3, tj = tap & 7;
+                    const int e0 = wxi * 32 + 16 * kk + 8 * h + (tj & 4);
+                    const __bf16 *ph = thin2 + (0 * 4 + (tj & 3)) * TCOPY + (yl + ti) * TPITCH + e0;
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ph);
+                    const bf16x4 a1 = *reinterpret_cast<const bf16x4 *>(ph + 4);
+                    Bh[tt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (PREC != 1) {
+                        const __bf16 *pl = ph + 4 * TCOPY;
+                        const bf16x4 b0 = *reinterpret_cast<const bf16x4 *>(pl);
+                        const bf16x4 b1 = *reinterpret_cast<const bf16x4 *>(pl + 4);
+                        Bl[tt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int R = 0; R < MT; ++R) {
+                    const int gg = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+                    bf16x4 part[2][2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = 16 * kk + 8 * h + 4 * half + qq;
+                        const int slot = (4 * gg + pp) ^ ((row >> 1) & 7);
+                        const __bf16 *src = wimg + (size_t)(R * 2) * IMG_ELEMS + row * 32 + slot * 4;
+                        part[0][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4 *)(src));
+                        if (PREC != 1 && LOUT != LAY_BLK16)
+                            part[1][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4 *)(src + IMG_ELEMS));
+                    }
+                    const bf16x8 Ah = __builtin_shufflevector(part[0][0], part[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8 Al;
+                    if (PREC != 1 && LOUT != LAY_BLK16) Al = __builtin_shufflevector(part[1][0], part[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        if (PREC != 1) {
+                            if (LOUT != LAY_BLK16) dacc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[tt], dacc[R][tt], 0, 0, 0);
+                            dacc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[tt], dacc[R][tt], 0, 0, 0);
+                            if (PREC == 2 && LOUT != LAY_BLK16) dacc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bl[tt], dacc[R][tt], 0, 0, 0);
+                        }
+                        dacc[R][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[tt], dacc[R][tt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         if (MODE == MODE_BWD && !p.do_synth) continue;
         if CDL_DBG(p.dbg, 2) { ring[0][0] += acc[0][0] + acc[MT - 1][15]; continue; }
 
@@ -743,6 +891,7 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     }
     __syncthreads();                         // every wave is done with the thin copies and the slabs
     if (MODE == MODE_BWD) stage_load(t + gridDim.x);   // (the backward stage has no registers to spare earlier)
+    if constexpr (DA) stage2_load(t + gridDim.x);
     if (MODE == MODE_BWD && tid < M) {
         float sacc = 0.0f;
 #pragma unroll
@@ -757,7 +906,31 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
         }
     }
     stage_store();                           // next tile's thin copies (registers loaded above)
+    if constexpr (DA) stage2_store();
     }   // tile loop
+    if constexpr (DA) {
+        // sum the waves through LDS (wave 0 stores, the others add in turn: fixed order, every lane owns its words) and
+        // write this workgroup's partial in k_wgrad_reduce's layout, operator slot 0
+        float *red = reinterpret_cast<float *>(smem);                           // [M][64] over the thin copies
+        for (int w = 0; w < NW; ++w) {
+            __syncthreads();
+            if (wid == w) {
+#pragma unroll
+                for (int R = 0; R < MT; ++R)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const int ch = 32 * R + (v & 3) + 8 * (v >> 2) + 4 * h;
+                            float *dstw = &red[ch * 64 + 32 * tt + c];
+                            *dstw = (w == 0 ? 0.0f : *dstw) + dacc[R][tt][v];
+                        }
+            }
+        }
+        __syncthreads();
+        float *dst = p.da_partial + (size_t)blockIdx.x * 2 * M * 64;
+        for (int i = tid; i < M * 64; i += NT) dst[i] = red[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -912,20 +1085,14 @@ __global__ __launch_bounds__(256) void k_support_map(const float *__restrict__ z
 // 64 x 16 pixel tile as 2 x 2 waves of 32 x 8; workgroups stride over the tiles keeping their
 // [ch][tap] accumulators in registers; waves are then summed through LDS in a fixed order and one
 // partial per workgroup is written.
-constexpr int GW_TH = 16;                    // tile rows of the filter-gradient kernel
-constexpr int GW_RTH = GW_TH + 2 * HALO;     // 22
-constexpr int TROWS = GW_RTH + 1;            // halo rows + the (never used) i = 7 pad row
-constexpr int TPITCH = 72;                   // bf16 elements per row of a shifted copy (144 B)
-constexpr int TCOPY = TROWS * TPITCH;
-constexpr int WG_THIN_BYTES = 2 * 2 * 4 * TCOPY * 2;      // [op][hl][shift] copies               (52992)
-constexpr int IMG_ELEMS = 32 * 32;           // one [32 px][32 ch] bf16 image (2 KB)
-
 struct WgradParams {
     const float *X[2];       // fat (N,M,H,W), nullptr = operator absent
     const float *T[2];       // thin (N,H,W)
     float *partial;          // (gridDim.x, 2, M, 64)
     int N, H, W, tilesX, tilesY, numTiles;
     int rev;                 // tiles from last to first
+    int single;              // one operator (X[1] = X[0], T[1] = T[0]): both wave groups work on it, on alternate tiles; their
+                             // two partial slots are added by k_wgrad_reduce
 };
 
 //   LAY: layout of the fat operands X[0], X[1] (LAY_*)
@@ -942,8 +1109,6 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
     const int c = lane & 31, h = lane >> 5;
     const size_t HW = (size_t)p.H * p.W;
     __bf16 *wimg = imgs + (size_t)wid * (MT * 2) * IMG_ELEMS;
-    const bool active = p.X[op] != nullptr;
-
     f32x16 acc[MT][2];
 #pragma unroll
     for (int R = 0; R < MT; ++R)
@@ -955,11 +1120,15 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
     // zero the thin copies once: pad elements are read (into ignored tap columns) and must stay finite
     for (int i = tid; i < WG_THIN_BYTES / 16; i += 512) reinterpret_cast<uint4 *>(dsm)[i] = make_uint4(0, 0, 0, 0);
 
-    for (int t = blockIdx.x; t < p.numTiles; t += gridDim.x) {
+    const bool present = p.X[op] != nullptr;
+    const int nsteps = p.single ? (p.numTiles + 1) / 2 : p.numTiles;
+    for (int t0 = blockIdx.x; t0 < nsteps; t0 += gridDim.x) {
+        const int t = p.single ? 2 * t0 + op : t0;         // single operator: the wave groups take alternate tiles
+        const bool active = present && t < p.numTiles;    // (per wave group)
         int bid = p.rev ? p.numTiles - 1 - t : t;
         const int txi = bid % p.tilesX; bid /= p.tilesX;
         const int tyi = bid % p.tilesY;
-        const int n = bid / p.tilesY;
+        const int n = active ? bid / p.tilesY : 0;
         const int tx0 = txi * TW, ty0 = tyi * GW_TH;
         __syncthreads();                                  // previous tile's readers are done
         if (active) {                                     // each group of 256 threads stages its own thin tile
@@ -1112,22 +1281,26 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
 // dw[ch][i'][j'] = alpha * sum_g partial[g][op][ch][8(i'+off) + (j'+off)].  32 outputs per workgroup,
 // 32 strided partial sums each (1024 threads: the kernel is latency-bound, 16 loads per thread), combined
 // in a fixed order (deterministic).
+//   merge: both operator slots hold partials of ONE gradient (single-operator launches of k_wgrad2d): dw0 gets their sum
 __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float *__restrict__ partial, int G,
                                                        float *__restrict__ dw0, float alpha0,
-                                                       float *__restrict__ dw1, float alpha1, int M, int P)
+                                                       float *__restrict__ dw1, float alpha1, int M, int P, int merge = 0)
 {
     __shared__ float red[32][33];
     const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int t = blockIdx.x * 32 + o;
     const int per = M * P * P;
-    const bool live = t < 2 * per;
+    const bool live = t < (merge ? per : 2 * per);
     float sum = 0.0f;
     int op = 0, r = 0;
     if (live) {
         op = t / per; r = t % per;
         const int ch = r / (P * P), ij = r % (P * P), off = (7 - P) / 2;
         const int tap = 8 * (ij / P + off) + (ij % P + off);
-        for (int g = part; g < G; g += 32) sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
+        for (int g = part; g < G; g += 32) {
+            sum += partial[((size_t)(g * 2 + op) * M + ch) * 64 + tap];
+            if (merge) sum += partial[((size_t)(g * 2 + 1) * M + ch) * 64 + tap];
+        }
     }
     red[part][o] = sum;
     __syncthreads();
@@ -1207,8 +1380,17 @@ inline Flags parse_flags(int precision)
 template <int MT, int PREC, int MODE, int LIN, int LOUT>
 int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
 {
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT>, LDS_STAGE)) return rc;
-    k_stage<MT, PREC, MODE, LIN, LOUT><<<grid, NT, LDS_STAGE, st>>>(p);
+    if constexpr (MODE == MODE_BWD && TH == GW_TH) {
+        if (p.r2) {                                          // the reverse stage that also accumulates dA_k
+            if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT, true>, LDS_STAGE + LDS_DA)) return rc;
+            k_stage<MT, PREC, MODE, LIN, LOUT, true><<<grid, NT, LDS_STAGE + LDS_DA, st>>>(p);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : -(int)e;
+        }
+    }
+    if (p.r2) return CDL_EUNSUPPORTED;
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT>, LDS_STAGE + CDL_LDS_PAD)) return rc;
+    k_stage<MT, PREC, MODE, LIN, LOUT><<<grid, NT, LDS_STAGE + CDL_LDS_PAD, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1243,14 +1425,19 @@ int launch_stage(const FusedParams &p, int mode, int lin, int lout, dim3 grid, h
     return launch_stage_lay<MT, PREC, MODE_BWD>(p, lin, lout, grid, st);
 }
 
-int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, const Flags &f, hipStream_t st)
+// persistent workgroups: one per CU (most of its LDS each), striding over the tiles
+int stage_grid(const cdl_geom *, const FusedParams &p)
 {
-    // persistent workgroups: one per CU (128 KB of LDS each), striding over the tiles
     const size_t tiles = (size_t)p.N * p.tilesX * p.tilesY;
     size_t cus = (size_t)cdl_cu_count();
     const int cap = cdl_opts().fused_grid;                   // experiments only: fewer persistent workgroups
     if (cap > 0 && (size_t)cap < cus) cus = (size_t)cap;
-    dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    return (int)(tiles < cus ? tiles : cus);
+}
+
+int dispatch_stage(const cdl_geom *g, const FusedParams &p, int mode, const Flags &f, hipStream_t st)
+{
+    dim3 grid((unsigned)stage_grid(g, p));
     if (g->M == 64)
         return f.prec == 0   ? launch_stage<2, 0>(p, mode, f.lin, f.lout, grid, st)
                : f.prec == 1 ? launch_stage<2, 1>(p, mode, f.lin, f.lout, grid, st)
@@ -1356,13 +1543,16 @@ int cdl_fused2d_iter_fwd(const cdl_geom *g, const float *r, const float *zin, co
     return dispatch_stage(g, p, zin ? MODE_FWD : MODE_FIRST, f, S(stream));
 }
 
-int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
-                          const void *frags, float *du_out, float *patches, float *dtau_partial,
-                          int do_synth, int precision, void *stream)
+// r2 != nullptr: the launch also produces dA = alpha * du_out (x) im2col(r2) (cdl_fused2d_wgrad's first operator pair, same
+// arithmetic), through `workspace` (cdl_fused2d_wgrad_workspace_floats) -- one fat read of du_out less than the two-launch form
+static int stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map, const void *frags,
+                     float *du_out, float *patches, float *dtau_partial, int do_synth, int precision, const float *r2,
+                     float alpha, float *dA, float *workspace, void *stream)
 {
     if (!fused_shape_ok(g)) return CDL_EUNSUPPORTED;
     if (!thin || !map || !frags || !du_out || !dtau_partial || du_out == base) return CDL_EINVAL;
     if (do_synth && !patches) return CDL_EINVAL;
+    if (r2 && (!dA || !workspace)) return CDL_EINVAL;
     const Flags f = parse_flags(precision);
     if (!f.ok) return CDL_EINVAL;
     FusedParams p = {};
@@ -1372,7 +1562,22 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
     p.patches = patches; p.sgn = 1.0f; p.do_synth = do_synth ? 1 : 0; CDL_DBG_FIELD(p.dbg = debug_flags();)
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = tiles_y(g);
-    return dispatch_stage(g, p, MODE_BWD, f, S(stream));
+    p.r2 = r2; p.da_partial = workspace;
+    int rc = dispatch_stage(g, p, MODE_BWD, f, S(stream));
+    if (rc || !r2) return rc;
+    const int G = stage_grid(g, p);
+    const int total = 2 * g->M * g->Ph * g->Pw;
+    k_wgrad_reduce<<<(total + 31) / 32, 1024, 0, S(stream)>>>(workspace, G, dA, alpha, nullptr, 0.0f, g->M, g->Ph);
+    CDL_LAUNCH_CHECK();
+    return 0;
+}
+
+int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
+                          const void *frags, float *du_out, float *patches, float *dtau_partial,
+                          int do_synth, int precision, void *stream)
+{
+    return stage_bwd(g, thin, base, map, frags, du_out, patches, dtau_partial, do_synth, precision, nullptr, 0.0f, nullptr,
+                     nullptr, stream);
 }
 
 int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c, float *dt0,
@@ -1403,11 +1608,17 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     WgradParams p = {};
     p.rev = f.rev;
     p.X[0] = X0; p.T[0] = T0; p.X[1] = X1; p.T[1] = T1;
+    p.single = (X0 != nullptr) != (X1 != nullptr);
+    if (p.single) {                                         // one gradient: both wave groups on it
+        if (!X0) { X0 = X1; T0 = T1; alpha0 = alpha1; dw0 = dw1; X1 = nullptr; }
+        p.X[0] = p.X[1] = X0; p.T[0] = p.T[1] = T0;
+    }
     p.partial = workspace;
     p.N = g->N; p.H = g->H; p.W = g->W;
     p.tilesX = tiles_x(g); p.tilesY = (g->H + GW_TH - 1) / GW_TH;
     p.numTiles = p.N * p.tilesX * p.tilesY;
-    const int G = wgrad_grid(g);
+    int G = wgrad_grid(g);
+    if (p.single && G > (p.numTiles + 1) / 2) G = (p.numTiles + 1) / 2;
     int rc;
     if (g->M == 64)
         rc = f.prec == 0 ? launch_wgrad<2, 0>(p, f.lin, G, S(stream))
@@ -1418,7 +1629,7 @@ int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float
     if (rc) return rc;
     const int total = 2 * g->M * g->Ph * g->Pw;
     k_wgrad_reduce<<<(total + 31) / 32, 1024, 0, S(stream)>>>(workspace, G, X0 ? dw0 : nullptr, alpha0,
-                                                             X1 ? dw1 : nullptr, alpha1, g->M, g->Ph);
+                                                             X1 ? dw1 : nullptr, alpha1, g->M, g->Ph, p.single);
     CDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1621,10 +1832,15 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
     for (int k = K - 1, flip = 0; k >= 0; --k, flip ^= 1) {
         const void *fk = static_cast<const char *>(frags) + (size_t)k * fb;
         float *duk = du[flip];
+        // dA_k = -du_k (x) r_k (k = 0: du_0 (x) yp) rides in the reverse stage, which has du_k in its registers: du_k is
+        // read once (by stage k-1), not twice -- 5.1 fat passes per iteration instead of 6.1 (CDL_FUSED_DA=0: the two-launch
+        // form, for A/B runs)
+        const bool ride = TH == GW_TH && cdl_opts().fused_da;
         {
             TimingScope ts(1, S(stream));
-            rc = cdl_fused2d_stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
-                                       sprec | CDL_LAYOUT_IN(k == K - 1 ? LAY_NCHW : L) | CDL_LAYOUT_OUT(L), stream);
+            rc = stage_bwd(g, thin, base, maps[k], fk, duk, patches, dtau_partial, k >= 1,
+                           sprec | CDL_LAYOUT_IN(k == K - 1 ? LAY_NCHW : L) | CDL_LAYOUT_OUT(L),
+                           ride ? (k >= 1 ? r[k - 1] : yp) : nullptr, k >= 1 ? -1.0f : 1.0f, dA[k], wgrad_ws, stream);
         }
         if (rc) return rc;
         rc = cdl_fused2d_dtau_reduce(g, dtau_partial, c, dt + (size_t)k * 2 * M, dt + (size_t)k * 2 * M + M, stream);
@@ -1634,11 +1850,13 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
             if (rc) return rc;
             {
                 TimingScope ts(2, S(stream));
-                rc = cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws,
-                                       wprec | CDL_LAYOUT_IN(L), stream);
+                rc = ride ? cdl_fused2d_wgrad(g, z[k - 1], q, 1.0f, dB[k], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
+                                              wprec | CDL_LAYOUT_IN(L), stream)
+                          : cdl_fused2d_wgrad(g, duk, r[k - 1], -1.0f, dA[k], z[k - 1], q, 1.0f, dB[k], wgrad_ws,
+                                              wprec | CDL_LAYOUT_IN(L), stream);
             }
             thin = q;
-        } else {
+        } else if (!ride) {
             rc = cdl_fused2d_wgrad(g, duk, yp, 1.0f, dA[0], nullptr, nullptr, 0.0f, nullptr, wgrad_ws,
                                    wprec | CDL_LAYOUT_IN(L), stream);
         }

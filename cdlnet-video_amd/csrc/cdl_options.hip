@@ -40,6 +40,7 @@ const cdl_options *load_options()
     o->no_pipelined_synthesis = getenv("CDL_NO_PIPELINED_SYNTHESIS") ? 1 : 0;
     o->fused_snake = env_flag_off("CDL_FUSED_SNAKE");
     o->fused_grid = env_int("CDL_FUSED_GRID", 0);
+    o->fused_da = env_flag_off("CDL_FUSED_DA");
     o->scalar_assemble = env_int("CDL_SCALAR_ASSEMBLE", 0) ? 1 : 0;
     o->fusedg_strip = env_int("CDL_FUSEDG_STRIP", 0) ? 1 : 0;
     o->fusedg_bwd_prec = env_int("CDL_FUSEDG_PREC", -1);

