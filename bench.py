@@ -157,11 +157,14 @@ def kernel_probe(cva, net, batch, size, reps=5):
             f"k_stage<FWD,{prec}> (z'=ST(z-A r), patches of B z', support map)":
                 (lambda: o.fused_iter(g, x, zl, tau, frags, -1.0, patches, prec, out=outl, map_out=bits,
                                       lay_in=lay, lay_out=lay), K, 2 * fat + mapb + 2 * th),
-            f"k_stage<BWD,{prec}> (du=[z'!=0](du'+B^T q), dtau, patches of A^T du)":
+            # the reverse sweep as cdl_fused2d_backward runs it: dA_k rides in the stage (du_k is read once, by the next
+            # stage), dB_k is a single-operator filter-gradient launch
+            f"k_stage<BWD,{prec}> (du=[z'!=0](du'+B^T q), dtau, patches of A^T du, dA_k)":
                 (lambda: o.fused_stage_bwd(g, x, gl, bits, frags, patches, dtp, True, prec, out=outl,
-                                           lay_in=lay, lay_out=lay), K, 2 * fat + mapb + 2 * th),
-            f"k_wgrad2d<{prec}> (dA_k and dB_k)":
-                (lambda: o.fused_wgrad(g, ws, gl, x, -1.0, zl, x, 1.0, prec, layout=lay), K, 2 * fat + 2 * th),
+                                           lay_in=lay, lay_out=lay, r2=x, alpha=-1.0, workspace=ws),
+                 K, 2 * fat + mapb + 3 * th),
+            f"k_wgrad2d<{prec}> (dB_k)":
+                (lambda: o.fused_wgrad(g, ws, zl, x, 1.0, precision=prec, layout=lay), K, fat + th),
             "k_assemble (thin)": (lambda: o.fused_assemble(g, patches, None, x, 1.0, out=thin), 2 * K, 3 * th),
             "k_prep (weights -> bf16 fragments)": (lambda: o.fused_prep(w, w), 2 * K, 0),
         }

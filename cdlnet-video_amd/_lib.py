@@ -76,6 +76,7 @@ SIGNATURES = {
     "cdl_fused2d_timing_read": [ctypes.POINTER(ctypes.c_double), _IP],
     "cdl_fused2d_assemble": [_G, _P, _P, _P, _F, _P, _P],
     "cdl_fused2d_stage_bwd": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "cdl_fused2d_stage_bwd_da": [_G, _P, _P, _P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _I, _P],
     "cdl_fused2d_dtau_reduce": [_G, _P, _P, _P, _P, _P],
     "cdl_fused2d_wgrad": [_G, _P, _P, _F, _P, _P, _P, _F, _P, _P, _I, _P],
     "cdl_fused2d_forward": [_G, _I] + [_P] * 11 + [_I, _P],

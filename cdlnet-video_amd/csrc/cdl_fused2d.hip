@@ -1580,6 +1580,15 @@ int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *bas
                      nullptr, stream);
 }
 
+int cdl_fused2d_stage_bwd_da(const cdl_geom *g, const float *thin, const float *base, const unsigned *map,
+                             const void *frags, float *du_out, float *patches, float *dtau_partial, int do_synth,
+                             const float *r2, float alpha, float *dA, float *workspace, int precision, void *stream)
+{
+    if (!r2 || !dA || !workspace) return CDL_EINVAL;
+    return stage_bwd(g, thin, base, map, frags, du_out, patches, dtau_partial, do_synth, precision, r2, alpha, dA, workspace,
+                     stream);
+}
+
 int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c, float *dt0,
                             float *dt1, void *stream)
 {

@@ -669,9 +669,11 @@ def fused_tiles(g: Geometry) -> int:
 
 
 def fused_stage_bwd(g: Geometry, thin, base, gate, frags, patches, dtau_partial, do_synth,
-                    precision="split3", out=None, lay_in="nchw", lay_out="nchw"):
+                    precision="split3", out=None, lay_in="nchw", lay_out="nchw", r2=None, alpha=1.0, workspace=None):
     """One reverse-sweep stage: du = [z' != 0] * (base + corr(thin; W1)); patches = W2^T du.  `gate` is the
-    bit map of z' (int32, from the forward or fused_support_map) or z' itself (the map is built first)."""
+    bit map of z' (int32, from the forward or fused_support_map) or z' itself (the map is built first).
+    With `r2` (thin) and `workspace` (fused_wgrad_workspace) the launch also accumulates dA = alpha * du (x) im2col(r2)
+    (cdl_fused2d_stage_bwd_da) and (du, dA) is returned."""
     thin = _dev(thin, "thin")
     if base is not None and lay_in == "nchw":
         base = _dev(base, "base")
@@ -681,10 +683,18 @@ def fused_stage_bwd(g: Geometry, thin, base, gate, frags, patches, dtau_partial,
     if out is None:
         out = fused_code_buffer(g, lay_out, thin.device)[0]
     gs = g.c_struct()
+    flags = PRECISION[precision] | _lay_in(lay_in) | _lay_out(lay_out)
+    if r2 is not None:
+        r2 = _dev(r2, "r2")
+        dA = torch.empty(g.filter_shape(), device=thin.device, dtype=torch.float32)
+        rc = _lib.lib().cdl_fused2d_stage_bwd_da(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate), _ptr(frags),
+                                                 _ptr(out), _ptr(patches), _ptr(dtau_partial), int(bool(do_synth)),
+                                                 _ptr(r2), float(alpha), _ptr(dA), _ptr(workspace), flags, _stream())
+        _lib.check(rc, "cdl_fused2d_stage_bwd_da")
+        return out, dA
     rc = _lib.lib().cdl_fused2d_stage_bwd(ctypes.byref(gs), _ptr(thin), _ptr(base), _ptr(gate),
                                           _ptr(frags), _ptr(out), _ptr(patches), _ptr(dtau_partial),
-                                          int(bool(do_synth)),
-                                          PRECISION[precision] | _lay_in(lay_in) | _lay_out(lay_out), _stream())
+                                          int(bool(do_synth)), flags, _stream())
     _lib.check(rc, "cdl_fused2d_stage_bwd")
     return out
 

@@ -350,6 +350,15 @@ size_t cdl_fused2d_tiles(const cdl_geom *g);               /* workgroups (= dtau
 int cdl_fused2d_stage_bwd(const cdl_geom *g, const float *thin, const float *base /*nullable*/,
                           const unsigned *map /*of z_{k+1}*/, const void *frags, float *du_out,
                           float *patches, float *dtau_partial, int do_synth, int precision, void *stream);
+/* The same stage with the analysis-filter gradient of the iteration riding in it (what autograd of net.py:87 computes from
+ * du_k and r_k): dA = alpha * sum_px du_out (x) im2col(r2) -- cdl_fused2d_wgrad's product, taken from the stage's registers
+ * instead of a second fat read of du_out.  du_out / patches / dtau_partial are bit-identical to cdl_fused2d_stage_bwd's;
+ * workspace: cdl_fused2d_wgrad_workspace_floats(g).  The whole-sweep entry point cdl_fused2d_backward uses this form
+ * (5.1 instead of 6.1 fat passes per iteration; CDL_FUSED_DA=0 restores the two-launch form for A/B runs). */
+int cdl_fused2d_stage_bwd_da(const cdl_geom *g, const float *thin, const float *base /*nullable*/,
+                             const unsigned *map, const void *frags, float *du_out, float *patches,
+                             float *dtau_partial, int do_synth, const float *r2 /*(N,1,H,W)*/, float alpha,
+                             float *dA /*(M,1,P,P)*/, float *workspace, int precision, void *stream);
 /* dt0[m] = sum over workgroups; dt1[m] = sum_n c[n] * (sum over the workgroups of image n); c nullable */
 int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const float *c /*N*/,
                             float *dt0 /*M*/, float *dt1 /*M*/, void *stream);

@@ -142,6 +142,20 @@ def test_fused_backward_stage_vs_generic(N, M, P, H, W, masked, precision, tol):
         check(f"{tag} {name} dt", dt, dt_ref, 4 * tol)
         du2 = o.fused_stage_bwd(geom, thin, b, gate, frags, None, dtp, False, precision)
         assert torch.equal(du2, du)
+        # the same stage with the analysis-filter gradient riding in it (cdl_fused2d_stage_bwd_da): du, patches and dtau
+        # bit for bit, dA = alpha * du (x) im2col(r2) against the generic filter gradient of the du it produced
+        r2 = torch.randn(N, 1, H, W, generator=gen).cuda()
+        ws = o.fused_wgrad_workspace(geom, "cuda")
+        patches3, dtp3 = torch.full_like(patches, float("nan")), torch.empty_like(dtp)
+        du3, dA = o.fused_stage_bwd(geom, thin, b, gate, frags, patches3, dtp3, True, precision, r2=r2, alpha=-1.0,
+                                    workspace=ws)
+        assert torch.equal(du3, du) and torch.equal(patches3, patches) and torch.equal(dtp3, dtp)
+        check(f"{tag} {name} dA riding in the stage", dA, o.wgrad(geom, du, r2, -1.0), tol)
+        dA1 = o.fused_wgrad(geom, ws, du, r2, -1.0, precision=precision)[0]       # the two-launch form, single operator
+        check(f"{tag} {name} dA stage vs k_wgrad2d", dA, dA1, 2e-6 if precision == "split3" else tol)
+        _, dA2 = o.fused_stage_bwd(geom, thin, b, gate, frags, patches3, dtp3, True, precision, r2=r2, alpha=-1.0,
+                                   workspace=ws)
+        assert torch.equal(dA2, dA)                                               # reproducible bit for bit
 
 
 @pytest.mark.parametrize("N,M,P,H,W,masked", BWD_SHAPES + [(3, 64, 7, 64, 128, False)])

@@ -56,12 +56,14 @@ def main():
             cases[f"k_stage<FWD>[{prec},{lay},+map]"] = (
                 lambda zl=zl, out=out, prec=prec, kw=kw: o.fused_iter(g, r, zl, tau, frags, -1.0, patches, prec, out=out, map_out=bits, **kw),
                 2 * fat + mapb + 2 * th)
-            cases[f"k_stage<BWD>[{prec},{lay}]"] = (
-                lambda gl=gl, out=out, prec=prec, kw=kw: o.fused_stage_bwd(g, r, gl, bits, frags, patches, dtp, True, prec, out=out, **kw),
-                2 * fat + mapb + 2 * th)
-            cases[f"k_wgrad2d[{prec},{lay}]"] = (
-                lambda gl=gl, zl=zl, prec=prec, lay=lay: o.fused_wgrad(g, ws, gl, r, -1.0, zl, r, 1.0, prec, layout=lay),
-                2 * fat + 2 * th)
+            # the forms cdl_fused2d_backward launches: dA_k riding in the reverse stage, dB_k alone in k_wgrad2d
+            cases[f"k_stage<BWD>[{prec},{lay},+dA]"] = (
+                lambda gl=gl, out=out, prec=prec, kw=kw: o.fused_stage_bwd(g, r, gl, bits, frags, patches, dtp, True, prec, out=out,
+                                                                           r2=r, alpha=-1.0, workspace=ws, **kw),
+                2 * fat + mapb + 3 * th)
+            cases[f"k_wgrad2d[{prec},{lay},dB only]"] = (
+                lambda zl=zl, prec=prec, lay=lay: o.fused_wgrad(g, ws, zl, r, 1.0, precision=prec, layout=lay),
+                fat + th)
         cases[f"k_stage<FWD>[split3,{lay},no map]"] = (
             lambda zl=zl, out=out, kw=kw: o.fused_iter(g, r, zl, tau, frags, -1.0, patches, "split3", out=out, **kw), 2 * fat + 2 * th)
         cases[f"k_stage<FIRST>[split3,{lay}]"] = (

@@ -26,8 +26,8 @@ LAYS = {0: "nchw", 1: "blocked", 2: "blocked_bf16"}
 
 
 def label(name):
-    m = re.search(r"k_stage<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)        # <MT, PREC, MODE, LIN, LOUT>
-    if m:
+    m = re.search(r"k_stage<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)   # <MT, PREC, MODE, LIN, LOUT, DA>
+    if m:                                                    # (the reverse stage is profiled in its shipped form: with dA_k)
         return f"k_stage<{MODES[int(m.group(3))]},{PRECS[int(m.group(2))]}>"
     m = re.search(r"k_wgrad2d<(\d+), (\d+), (\d+)>", name)                      # <MT, PREC, LAY>
     if m:
