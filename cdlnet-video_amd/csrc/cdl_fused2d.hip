@@ -22,10 +22,12 @@
 // product is hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error ~2^-16 per product, random
 // sign; measured end-to-end parity is recorded in DESIGN.md).  PREC = 1 drops the lo terms (plain bf16).
 //
-// Work decomposition: workgroup = 512 threads = 8 waves (2 per SIMD, so one wave's memory waits are
-// covered by its partner's MFMAs) = 64 x 32 pixel tile of one image (2 x 4 waves of 32 x 8);
-// grid = N * tilesY * tilesX.  Weight fragments live in LDS (32 KB, shared by the 8 waves).  Each
-// workgroup writes its (32+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
+// Work decomposition: workgroup = 256 threads = 4 waves, ONE per SIMD, = 64 x 16 pixel tile of one image (2 x 2 waves of
+// 32 x 8); persistent grid, one workgroup per CU.  (Rounds 1-2: 8 waves on 64 x 32 tiles, two per SIMD so that a wave's memory
+// waits were covered by its partner -- -DCDL_WY=4 still builds that form.  One wave per SIMD costs the forward nothing and the
+// reverse stage 11 %, and frees the registers -- up to 512 per wave -- and the LDS that let the reverse stage accumulate
+// dA_k itself: one fat pass per iteration less)  Weight fragments live in LDS (32 KB).  Each
+// workgroup writes its (16+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
 // patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
 #include <atomic>
@@ -44,18 +46,15 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #ifndef CDL_WY
-#define CDL_WY 2
-#endif
-#ifndef CDL_LDS_PAD
-#define CDL_LDS_PAD 0
+#define CDL_WY 2                            // wave rows per workgroup: 2 (64 x 16 tiles, one wave per SIMD) or 4 (64 x 32, two)
 #endif
 constexpr int WX = 2, WY = CDL_WY;          // waves per workgroup along x / y
-constexpr int NW = WX * WY;                 // 8 waves
-constexpr int NT = 64 * NW;                 // 512 threads
+constexpr int NW = WX * WY;                 // 4 waves
+constexpr int NT = 64 * NW;                 // 256 threads
 constexpr int RB = 8;                       // row blocks (image rows) per wave
-constexpr int TW = 32 * WX, TH = RB * WY;   // 64 x 32 tile
+constexpr int TW = 32 * WX, TH = RB * WY;   // 64 x 16 tile
 constexpr int HALO = 3;                     // filters are embedded in a 7 x 7 (padded 8 x 8) tap grid
-constexpr int RTW = TW + 2 * HALO, RTH = TH + 2 * HALO;   // 70 x 38 residual tile / patch
+constexpr int RTW = TW + 2 * HALO, RTH = TH + 2 * HALO;   // 70 x 22 residual tile / patch
 constexpr int RTC = RTW + 2;                // columns kept in LDS (col 70 is the zero-weight pad tap)
 constexpr int PITCH = WY == 2 ? 28 : 44;    // bf16 elements per LDS column (>= RTH + 2; 56 / 88 B: 14 / 22 dwords between the columns of
                                             // neighbouring lanes -- conflict-free b64 reads)
@@ -1389,8 +1388,8 @@ int launch_stage_one(const FusedParams &p, dim3 grid, hipStream_t st)
         }
     }
     if (p.r2) return CDL_EUNSUPPORTED;
-    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT>, LDS_STAGE + CDL_LDS_PAD)) return rc;
-    k_stage<MT, PREC, MODE, LIN, LOUT><<<grid, NT, LDS_STAGE + CDL_LDS_PAD, st>>>(p);
+    if (int rc = cdl_ensure_dynamic_lds((const void *)k_stage<MT, PREC, MODE, LIN, LOUT>, LDS_STAGE)) return rc;
+    k_stage<MT, PREC, MODE, LIN, LOUT><<<grid, NT, LDS_STAGE, st>>>(p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
