@@ -26,7 +26,8 @@
 // 32 x 8); persistent grid, one workgroup per CU.  (Rounds 1-2: 8 waves on 64 x 32 tiles, two per SIMD so that a wave's memory
 // waits were covered by its partner -- -DCDL_WY=4 still builds that form.  One wave per SIMD costs the forward nothing and the
 // reverse stage 11 %, and frees the registers -- up to 512 per wave -- and the LDS that let the reverse stage accumulate
-// dA_k itself: one fat pass per iteration less)  Weight fragments live in LDS (32 KB).  Each
+// dA_k itself: one fat pass per iteration less)  Weight fragments: staged through LDS (32 KB) once per
+// workgroup, then resident in every wave's registers.  Each
 // workgroup writes its (16+6) x (64+6) partial synthesis patch; k_assemble sums the <= 4 overlapping
 // patches per pixel in a fixed order and applies mask / -yp.  Every reduction (col2im slabs, dtau,
 // filter gradients) is combined in a fixed order: results are bit-reproducible run to run.
@@ -503,7 +504,19 @@ __global__ __launch_bounds__(NT) void k_stage(FusedParams p)
     constexpr int OFF_AL = FA;                               // split3 only
     constexpr int OFF_BH = (PREC != 1 ? 2 * FA : FA);
     constexpr int OFF_BL = 2 * FA + FB;                      // split3 only
-    auto wfrag = [&](int f) { return __builtin_bit_cast(bf16x8, wl[f * 64 + lane]); };
+    // One wave per SIMD: every weight fragment of the launch lives in this wave's registers (32 x 4 at M = 64, split3; the
+    // 512-register budget has the room) -- with no partner wave on the SIMD, the LDS latency of a fragment read in front of
+    // (almost) every MFMA was most of the row block's time.  Two waves per SIMD: read from LDS where used.
+    constexpr bool WREG = WY == 2;
+    bf16x8 wreg[WREG ? NFRAG : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) wreg[f] = __builtin_bit_cast(bf16x8, wl[f * 64 + lane]);
+    }
+    auto wfrag = [&](int f) __attribute__((always_inline)) {
+        if constexpr (WREG) return wreg[f];
+        else return __builtin_bit_cast(bf16x8, wl[f * 64 + lane]);
+    };
 
     const int xl = wxi * 32 + c;             // tile-local pixel column of this lane
     float *rsum = rsum_all + ((wxi & 1) + 2 * (wyi & 1)) * SLAB;
