@@ -40,6 +40,33 @@
 
 #include "cdl_common.h"
 
+// This file is compiled TWICE (csrc/Makefile).  The default object carries the C ABI; the second one (-DCDL_F2D_WY4) is the
+// same code on 64 x 32 tiles with two waves per SIMD -- rounds 1-2's form -- with every entry point suffixed _wy4.  The
+// whole-sweep entry points of the default object hand sweeps with bf16 code STORAGE (CDL_LAY_BLK16) to it: those kernels
+// are compute-bound, and lose at one wave per SIMD what the fp32-storage sweep gains from it (28.5 against 26.5 ms/step).
+#ifdef CDL_F2D_WY4
+#define CDL_WY 4
+#define cdl_fused2d_assemble cdl_fused2d_assemble_wy4
+#define cdl_fused2d_backward cdl_fused2d_backward_wy4
+#define cdl_fused2d_code_bytes cdl_fused2d_code_bytes_wy4
+#define cdl_fused2d_dtau_reduce cdl_fused2d_dtau_reduce_wy4
+#define cdl_fused2d_forward cdl_fused2d_forward_wy4
+#define cdl_fused2d_frag_bytes cdl_fused2d_frag_bytes_wy4
+#define cdl_fused2d_iter_fwd cdl_fused2d_iter_fwd_wy4
+#define cdl_fused2d_map_words cdl_fused2d_map_words_wy4
+#define cdl_fused2d_patch_floats cdl_fused2d_patch_floats_wy4
+#define cdl_fused2d_prep cdl_fused2d_prep_wy4
+#define cdl_fused2d_stage_bwd cdl_fused2d_stage_bwd_wy4
+#define cdl_fused2d_stage_bwd_da cdl_fused2d_stage_bwd_da_wy4
+#define cdl_fused2d_support_map cdl_fused2d_support_map_wy4
+#define cdl_fused2d_supported cdl_fused2d_supported_wy4
+#define cdl_fused2d_tiles cdl_fused2d_tiles_wy4
+#define cdl_fused2d_timing cdl_fused2d_timing_wy4
+#define cdl_fused2d_timing_read cdl_fused2d_timing_read_wy4
+#define cdl_fused2d_wgrad cdl_fused2d_wgrad_wy4
+#define cdl_fused2d_wgrad_workspace_floats cdl_fused2d_wgrad_workspace_floats_wy4
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -1491,16 +1518,36 @@ int cdl_fused2d_supported(const cdl_geom *g) { return fused_shape_ok(g) ? 1 : 0;
 
 size_t cdl_fused2d_frag_bytes(int M) { return (size_t)2 * (M / 32) * 8 * 64 * 16; }
 
+// (buffers a caller sizes with these serve sweeps of either object: the larger of the two tile geometries)
+#ifndef CDL_F2D_WY4
+size_t cdl_fused2d_patch_floats_wy4(const cdl_geom *g);
+size_t cdl_fused2d_tiles_wy4(const cdl_geom *g);
+size_t cdl_fused2d_wgrad_workspace_floats_wy4(const cdl_geom *g);
+static size_t larger(size_t a, size_t b) { return a > b ? a : b; }
+#else
+static size_t larger(size_t a, size_t) { return a; }
+#endif
+
 size_t cdl_fused2d_patch_floats(const cdl_geom *g)
 {
     if (!fused_shape_ok(g)) return 0;
-    return (size_t)g->N * tiles_x(g) * tiles_y(g) * SLAB;
+    const size_t own = (size_t)g->N * tiles_x(g) * tiles_y(g) * SLAB;
+#ifndef CDL_F2D_WY4
+    return larger(own, cdl_fused2d_patch_floats_wy4(g));
+#else
+    return own;
+#endif
 }
 
 size_t cdl_fused2d_tiles(const cdl_geom *g)
 {
     if (!fused_shape_ok(g)) return 0;
-    return (size_t)g->N * tiles_x(g) * tiles_y(g);
+    const size_t own = (size_t)g->N * tiles_x(g) * tiles_y(g);
+#ifndef CDL_F2D_WY4
+    return larger(own, cdl_fused2d_tiles_wy4(g));
+#else
+    return own;
+#endif
 }
 
 int cdl_fused2d_prep(const float *wA, const float *wB, void *frags, int M, int P, void *stream)
@@ -1614,7 +1661,12 @@ int cdl_fused2d_dtau_reduce(const cdl_geom *g, const float *dtau_partial, const 
 size_t cdl_fused2d_wgrad_workspace_floats(const cdl_geom *g)
 {
     if (!fused_shape_ok(g)) return 0;
-    return (size_t)wgrad_grid(g) * 2 * g->M * 64;
+    const size_t own = (size_t)wgrad_grid(g) * 2 * g->M * 64;
+#ifndef CDL_F2D_WY4
+    return larger(own, cdl_fused2d_wgrad_workspace_floats_wy4(g));
+#else
+    return own;
+#endif
 }
 
 int cdl_fused2d_wgrad(const cdl_geom *g, const float *X0, const float *T0, float alpha0, float *dw0,
@@ -1721,8 +1773,16 @@ struct TimingScope {
 };
 }  // namespace
 
+#ifndef CDL_F2D_WY4
+extern "C" int cdl_fused2d_timing_wy4(int enable);
+extern "C" int cdl_fused2d_timing_read_wy4(double *ms_sum, int *count);
+#endif
+
 extern "C" int cdl_fused2d_timing(int enable)
 {
+#ifndef CDL_F2D_WY4
+    if (int rc = cdl_fused2d_timing_wy4(enable)) return rc;     // the sweeps of the other object (bf16 code storage) too
+#endif
     std::lock_guard<std::mutex> lk(g_timing.mu);
     g_timing.on.store(enable != 0, std::memory_order_relaxed);
     if (enable) {
@@ -1748,6 +1808,12 @@ extern "C" int cdl_fused2d_timing_read(double *ms_sum, int *count)
         ms_sum[pr.cls] += ms;
         ++count[pr.cls];
     }
+#ifndef CDL_F2D_WY4
+    double ms2[4];
+    int n2[4];
+    if (int rc = cdl_fused2d_timing_read_wy4(ms2, n2)) return rc;
+    for (int c = 0; c < 4; ++c) { ms_sum[c] += ms2[c]; count[c] += n2[c]; }
+#endif
     return 0;
 }
 
@@ -1785,6 +1851,17 @@ static int snake_enabled() { return cdl_opts().fused_snake; }
 // Sweeps: CDL_LAYOUT_IN(L) in `precision` selects the layout L of the tensors that stay inside the sweeps --
 // z_1 .. z_{K-1} (z[0..K-2]) and the du ping-pong buffers; z_K (z[K-1]) and g_z are always NCHW fp32.
 
+#ifndef CDL_F2D_WY4
+int cdl_fused2d_forward_wy4(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
+                            const float *const *wA, const float *const *wB, float *const *z, float *const *r,
+                            unsigned *const *maps, float *xp, void *frags, float *patches, int precision, void *stream);
+int cdl_fused2d_backward_wy4(const cdl_geom *g, int K, const float *yp, const float *mask, const float *c,
+                             const float *const *wA, const float *const *wB, const float *const *z,
+                             const float *const *r, const unsigned *const *maps, const float *g_xp, const float *g_z,
+                             float *const *dA, float *const *dB, float *dt, float *du0, float *du1, float *q, void *frags,
+                             float *patches, float *dtau_partial, float *wgrad_ws, int precision, void *stream);
+#endif
+
 int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *mask, const float *tau,
                         const float *const *wA, const float *const *wB, float *const *z, float *const *r,
                         unsigned *const *maps, float *xp, void *frags, float *patches, int precision,
@@ -1797,6 +1874,10 @@ int cdl_fused2d_forward(const cdl_geom *g, int K, const float *yp, const float *
     const Flags f = parse_flags(precision);
     if (!f.ok || f.lout != 0) return CDL_EINVAL;
     const int L = f.lin;
+#ifndef CDL_F2D_WY4
+    if (L == LAY_BLK16)                      // bf16 code storage: the two-waves-per-SIMD object (see the top of the file)
+        return cdl_fused2d_forward_wy4(g, K, yp, mask, tau, wA, wB, z, r, maps, xp, frags, patches, precision, stream);
+#endif
     const float *thin = yp;
     const size_t fb = cdl_fused2d_frag_bytes(g->M);
     int rc = prep_pairs(wA, wB, K, 1, frags, g->M, g->Ph, S(stream));       // (A_k, B_{k+1}) for every k, one launch
@@ -1839,6 +1920,11 @@ int cdl_fused2d_backward(const cdl_geom *g, int K, const float *yp, const float 
     const Flags f = parse_flags(precision);
     if (!f.ok || f.lout != 0) return CDL_EINVAL;
     const int L = f.lin;
+#ifndef CDL_F2D_WY4
+    if (L == LAY_BLK16)
+        return cdl_fused2d_backward_wy4(g, K, yp, mask, c, wA, wB, z, r, maps, g_xp, g_z, dA, dB, dt, du0, du1, q, frags,
+                                        patches, dtau_partial, wgrad_ws, precision, stream);
+#endif
     // the forward's last launch ran in direction (K-1)&1: stages take that one, filter gradients the other
     const int sdir = snake_enabled() ? (((K - 1) & 1) ? CDL_TILES_REVERSED : 0) : 0;
     const int wdir = snake_enabled() ? (sdir ^ CDL_TILES_REVERSED) : 0;

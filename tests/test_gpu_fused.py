@@ -149,7 +149,8 @@ def test_fused_backward_stage_vs_generic(N, M, P, H, W, masked, precision, tol):
         patches3, dtp3 = torch.full_like(patches, float("nan")), torch.empty_like(dtp)
         du3, dA = o.fused_stage_bwd(geom, thin, b, gate, frags, patches3, dtp3, True, precision, r2=r2, alpha=-1.0,
                                     workspace=ws)
-        assert torch.equal(du3, du) and torch.equal(patches3, patches) and torch.equal(dtp3, dtp)
+        # (the patch buffer is sized for the larger of the library's two tile geometries: its unused tail keeps the NaN fill)
+        assert torch.equal(du3, du) and torch.equal(patches3.nan_to_num(7.0), patches.nan_to_num(7.0)) and torch.equal(dtp3, dtp)
         check(f"{tag} {name} dA riding in the stage", dA, o.wgrad(geom, du, r2, -1.0), tol)
         dA1 = o.fused_wgrad(geom, ws, du, r2, -1.0, precision=precision)[0]       # the two-launch form, single operator
         check(f"{tag} {name} dA stage vs k_wgrad2d", dA, dA1, 2e-6 if precision == "split3" else tol)
@@ -350,15 +351,27 @@ def test_c_sweeps_are_bit_identical_to_stepwise_launches(layout):
     tau = o.thresholds(net.t.detach(), c, N)
     A = [m.weight.detach() for m in net.A]
     B = [m.weight.detach() for m in net.B]
+    # bf16 code storage: the whole-sweep entry points run the library's 64 x 32-tile object (two waves per SIMD: those sweeps
+    # are compute-bound), the step-wise ones its 64 x 16-tile object -- another partition of the col2im sums, so the thin
+    # tensors differ in their last bits and the bf16 rounding of the codes turns that into bf16-sized differences: agreement
+    # to storage accuracy there, bit for bit for the fp32 layouts
+    exact = layout != "blocked_bf16"
     xp1, z1, codes1, resid1, maps1 = loop._forward_fused(g, yp, None, tau, A, B, True, True, layout=layout)
     xp2, z2, codes2, resid2, maps2 = loop._forward_fused_stepwise(g, yp, None, tau, A, B, True, True, layout=layout)
-    assert len(maps1) == K and all(torch.equal(a, b) for a, b in zip(maps1, maps2))
     nchw = [o.fused_to_nchw(g, zc, layout if k < K - 1 else "nchw") for k, zc in enumerate(codes1)]
     assert all(torch.equal(m, o.fused_support_map(g, zc)) for m, zc in zip(maps1, nchw))   # forward map == builder
-    assert torch.equal(xp1, xp2) and torch.equal(z1, z2)
     nchw2 = [o.fused_to_nchw(g, zc, layout if k < K - 1 else "nchw") for k, zc in enumerate(codes2)]
-    assert all(torch.equal(a, b) for a, b in zip(nchw, nchw2)) and len(codes1) == K      # (padding pixels of a blocked buffer are never written)
-    assert all(torch.equal(a, b) for a, b in zip(resid1, resid2)) and len(resid1) == K - 1
+    assert len(maps1) == K and len(codes1) == K and len(resid1) == K - 1
+    if exact:
+        assert all(torch.equal(a, b) for a, b in zip(maps1, maps2))
+        assert torch.equal(xp1, xp2) and torch.equal(z1, z2)
+        assert all(torch.equal(a, b) for a, b in zip(nchw, nchw2))      # (padding pixels of a blocked buffer are never written)
+        assert all(torch.equal(a, b) for a, b in zip(resid1, resid2))
+    else:
+        check("bf16 storage, sweep vs step-wise xp", xp1, xp2, 5e-3)        # measured 2e-7: no rounding flipped at this size
+        check("bf16 storage, sweep vs step-wise z_K", z1, z2, 5e-3)
+        for a, b in zip(resid1, resid2):
+            check("bf16 storage, sweep vs step-wise r_k", a, b, 5e-3)
     xp3, z3, codes3, resid3, maps3 = loop._forward_fused(g, yp, None, tau, A, B, False, False, layout=layout)     # ping-pong buffers
     assert torch.equal(xp3, xp1) and torch.equal(z3, z1) and len(codes3) == 1 and resid3 == [] and maps3 == []
     g_xp = torch.randn(xp1.shape, generator=torch.Generator().manual_seed(2)).cuda()
@@ -368,9 +381,12 @@ def test_c_sweeps_are_bit_identical_to_stepwise_launches(layout):
         dA, dB = sweep(g, K, yp, None, c, A, B, codes1, resid1, g_xp, None, dt, maps=maps1, layout=layout)
         outs.append((dA, dB, dt))
     for k in range(K):
-        check(f"snake dA[{k}]", outs[0][0][k], outs[1][0][k], 2e-6)
-        check(f"snake dB[{k}]", outs[0][1][k], outs[1][1][k], 2e-6)
-    assert torch.equal(outs[0][2], outs[1][2])
+        check(f"snake dA[{k}]", outs[0][0][k], outs[1][0][k], 2e-6 if exact else 5e-3)
+        check(f"snake dB[{k}]", outs[0][1][k], outs[1][1][k], 2e-6 if exact else 5e-3)
+    if exact:
+        assert torch.equal(outs[0][2], outs[1][2])
+    else:
+        check("bf16 storage, sweep vs step-wise dt", outs[0][2], outs[1][2], 5e-3)
     again = []
     for _ in range(2):                                # the sweep itself is reproducible bit for bit
         dt = torch.zeros(K, 2, M, device="cuda")
