@@ -1172,13 +1172,26 @@ __global__ __launch_bounds__(512) void k_wgrad2d(WgradParams p)
         __syncthreads();                                  // previous tile's readers are done
         if (active) {                                     // each group of 256 threads stages its own thin tile
             const float *timg = p.T[op] + (size_t)n * HW;
-            for (int i = tid & 255; i < GW_RTH * RTW; i += 256) {
+            // all of a thread's elements are loaded (clamped addresses, no branches) before any is converted: one at a time
+            // was seven dependent global-load latencies per 64 x 16 tile, a quarter of the single-operator launch
+            constexpr int NSW = (GW_RTH * RTW + 255) / 256;
+            float tv[NSW];
+#pragma unroll
+            for (int k = 0; k < NSW; ++k) {
+                const int i = (tid & 255) + k * 256;
                 const int yy = i / RTW, xx = i % RTW;
                 const int gy = ty0 - HALO + yy, gx = tx0 - HALO + xx;
-                float v = 0.0f;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = timg[(size_t)gy * p.W + gx];
-                const __bf16 hh = (__bf16)v;
-                const __bf16 ll = (__bf16)(v - (float)hh);
+                const bool ok = i < GW_RTH * RTW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const float v = timg[ok ? (size_t)gy * p.W + gx : 0];
+                tv[k] = ok ? v : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < NSW; ++k) {
+                const int i = (tid & 255) + k * 256;
+                if (i >= GW_RTH * RTW) continue;
+                const int yy = i / RTW, xx = i % RTW;
+                const __bf16 hh = (__bf16)tv[k];
+                const __bf16 ll = (__bf16)(tv[k] - (float)hh);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     if (xx - s >= 0) {
