@@ -24,6 +24,34 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(cva._lib.Geom) == 15 * 4
 
 
+def test_exact_fp32_switch_is_per_thread_and_scoped():
+    """cdl_set_exact_fp32 (host-only state, no GPU needed): returns the previous setting, is private to the calling thread, and
+    the Python scopes restore what they found -- also when the body raises."""
+    import threading
+    lib = cva._lib.lib()
+    assert lib.cdl_set_exact_fp32(0) == 0
+    with cva.ops.exact_fp32():
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.cdl_set_exact_fp32(0)))
+        t.start()
+        t.join()
+        assert seen == [0]                                   # another thread still sees the default
+        assert lib.cdl_set_exact_fp32(1) == 1                # this one sees the scope
+        with cva.ops.exact_fp32(False):                      # a no-op block
+            assert lib.cdl_set_exact_fp32(1) == 1
+    assert lib.cdl_set_exact_fp32(0) == 0
+    with pytest.raises(ZeroDivisionError):
+        with cva.ops.exact_fp32():
+            1 / 0
+    assert lib.cdl_set_exact_fp32(0) == 0
+    assert "fp32" in cva.loop.ARITHMETIC
+    with cva.loop.precision_scope("fp32"):
+        assert cva.loop.PRECISION == "fp32"
+    assert cva.loop.PRECISION == "split3"
+    with pytest.raises(ValueError):
+        cva.loop.precision_scope("fp64")
+
+
 def test_no_cpu_compute_path():
     torch.manual_seed(0)
     net = cva.CDLNet(K=2, M=4, P=5, init=False)
